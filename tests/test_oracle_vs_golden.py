@@ -1,0 +1,31 @@
+"""Pins the CPU oracle to the reference: every shared case (tests/golden/cases.py) run through
+``oracle`` must reproduce the fixtures captured from the reference itself (gen_golden.py).
+fp32 on CPU both sides, different op order only -> 2e-5 relative / 2e-6 absolute."""
+import pytest
+import torch
+
+import cases
+import oracle
+from helpers import check_case, load_golden
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_matches_reference_fixture(name):
+    rec = cases.CASES[name](oracle, torch.device("cpu"))
+    check_case(name, rec, rtol=2e-5, atol=2e-6, grad_rtol=1e-4, grad_atol=1e-5)
+
+
+def test_state_dict_schema_matches_reference_counts():
+    """1301 keys / 365 unique tensors (CaSE), 663 / 296 (Masque)."""
+    from case_rg_amd.utils import make_vocab
+    v2i, i2v = make_vocab(200)
+    c = oracle.CaSE(4, 6, i2v, v2i, 32)
+    m = oracle.Masque(6, i2v, v2i, 32)
+    assert len(c.state_dict()) == 1301 and len(list(c.parameters())) == 365
+    assert len(m.state_dict()) == 663 and len(list(m.parameters())) == 296
+
+
+def test_greedy_fixture_is_not_degenerate():
+    for name in ("case_test", "masque_test"):
+        ans = load_golden(name)["answer"]
+        assert len(set(ans.reshape(-1).tolist())) > 2, "greedy fixture collapsed to one id"
