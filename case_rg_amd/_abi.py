@@ -1,0 +1,90 @@
+"""ctypes binding of libcase_hip.so (the C ABI declared in include/case_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import fails
+loudly, and every call that returns a negative code raises RuntimeError(case_last_error()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcase_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
+EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
+
+i32, i64, u64, f32, ptr = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, i64) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ld_aux", "batch1", "batch2",
+                                   "sa1", "sa2", "sb1", "sb2", "sc1", "sc2", "saux1", "saux2")] + \
+               [(n, i32) for n in ("a_kmajor", "b_kmajor", "in_dtype", "out_dtype", "epilogue", "split_k")] + \
+               [("alpha", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
+
+
+class SoftmaxDesc(C.Structure):
+    _fields_ = [("outer", i64), ("inner", i64), ("R", i64), ("C", i64), ("causal", i32), ("in_dtype", i32),
+                ("out_dtype", i32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
+
+
+# name -> argument types (all return int); mirrors include/case_hip.h one to one
+SIGNATURES = {
+    "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_embed_pos_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
+    "case_embed_pos_bwd": [ptr, ptr, ptr, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
+    "case_scale_add_rows": [ptr, ptr, ptr, i64, i64, i64, f32, i32, ptr],
+    "case_layernorm_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, f32, i32, ptr],
+    "case_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_softmax_fwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_softmax_bwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr],
+    "case_add": [ptr, ptr, ptr, i64, i32, ptr],
+    "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],
+    "case_mask_rows": [ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_colsum": [ptr, ptr, i64, i64, i32, ptr],
+    "case_cast": [ptr, ptr, i64, i32, i32, ptr],
+    "case_scale_cols": [ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_scale_cols_bwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_masked_mean_fwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
+    "case_masked_mean_bwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
+    "case_highway_gate_fwd": [ptr, ptr, i64, i64, i32, ptr],
+    "case_highway_gate_bwd": [ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_concat5_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_concat5_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_max_over_p_fwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
+    "case_max_over_p_bwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
+    "case_additive_scores_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, i32, ptr],
+    "case_additive_scores_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i64, i64, i32, ptr],
+    "case_copy_scatter_fwd": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
+    "case_copy_scatter_bwd": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
+    "case_nll_gather_fwd": [ptr, ptr, ptr, i64, i64, ptr],
+    "case_nll_gather_bwd": [ptr, ptr, ptr, ptr, i64, i64, ptr],
+    "case_row_argmax": [ptr, ptr, ptr, i64, i64, i64, ptr],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "case_rg_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C case_rg_amd/csrc`). There is no CPU or eager fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.case_version.restype = C.c_int
+    lib.case_last_error.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, code, lib.case_last_error().decode()))
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,317 @@
+// K7 additive-attention scores (fused tanh, never materialising [B,T,S,H]), K11 copy/pointer
+// scatter-add, K12 NLL gather, K13 row argmax.
+//
+// K7 is transcendental-issue bound (B*T*S*H tanh per pass; 2.5 G at cfg2), not MFMA or HBM work:
+//   forward   lanes = source position j (the H-sum stays in a register), uh tile transposed through LDS
+//   backward  two sweeps with lanes = h (coalesced uh reads, no cross-lane reductions, no atomics on the
+//             large tensors): sweep 1 owns (j, h) and sums over t -> d_uh and the d_v partials;
+//             sweep 2 owns (t, h) and sums over j -> d_wq.  tanh is recomputed in both.
+#include "common.h"
+
+namespace {
+
+template <bool FAST>
+__device__ __forceinline__ float tanh_t(float x) {
+  if constexpr (FAST) {
+    // 1 - 2 / (exp(2x) + 1); saturates cleanly for |x| large (exp -> inf gives 1, exp -> 0 gives -1)
+    const float e = __expf(2.f * x);
+    return 1.f - __fdividef(2.f, e + 1.f);
+  } else {
+    return tanhf(x);
+  }
+}
+
+constexpr int AJ = 64;   // source positions per workgroup (forward)
+constexpr int AH = 64;   // h chunk staged in LDS
+constexpr int ATW = 8;   // target rows per wave per chunk (4 waves -> 32 per chunk)
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void additive_fwd_kernel(const float* __restrict__ wq, const T* __restrict__ uh,
+                                                           const float* __restrict__ v, float* __restrict__ s, int64_t Tn,
+                                                           int64_t S, int64_t H) {
+  __shared__ float U[AJ][AH + 1];
+  __shared__ float W[4 * ATW][AH];
+  __shared__ float V[AH];
+  const int64_t b = blockIdx.y, j0 = (int64_t)blockIdx.x * AJ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t tc = 0; tc < Tn; tc += 4 * ATW) {
+    float acc[ATW];
+#pragma unroll
+    for (int i = 0; i < ATW; ++i) acc[i] = 0.f;
+    for (int64_t hc = 0; hc < H; hc += AH) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < AJ * AH; e += 256) {
+        const int jj = e / AH, hh = e % AH;
+        const int64_t j = j0 + jj, h = hc + hh;
+        U[jj][hh] = (j < S && h < H) ? Elem<T>::ld(uh + (b * S + j) * H + h) : 0.f;
+      }
+      for (int e = threadIdx.x; e < 4 * ATW * AH; e += 256) {
+        const int tt = e / AH, hh = e % AH;
+        const int64_t t = tc + tt, h = hc + hh;
+        W[tt][hh] = (t < Tn && h < H) ? wq[(b * Tn + t) * H + h] : 0.f;
+      }
+      if (threadIdx.x < AH) V[threadIdx.x] = (hc + threadIdx.x < H) ? v[hc + threadIdx.x] : 0.f;
+      __syncthreads();
+#pragma unroll 4
+      for (int hh = 0; hh < AH; ++hh) {
+        const float u = U[lane][hh], vv = V[hh];
+#pragma unroll
+        for (int i = 0; i < ATW; ++i) acc[i] += vv * tanh_t<FAST>(W[wave * ATW + i][hh] + u);
+      }
+    }
+    const int64_t j = j0 + lane;
+    if (j < S) {
+#pragma unroll
+      for (int i = 0; i < ATW; ++i) {
+        const int64_t t = tc + wave * ATW + i;
+        if (t < Tn) s[(b * Tn + t) * S + j] = acc[i];
+      }
+    }
+  }
+}
+
+// sweep 1: thread owns h (256 per workgroup), workgroup owns BJ source positions; sums over t.
+constexpr int BJ = 16;
+constexpr int BTC = 32;  // t chunk staged in LDS
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void additive_bwd_uh_kernel(const float* __restrict__ ds, const float* __restrict__ wq,
+                                                              const T* __restrict__ uh, const float* __restrict__ v,
+                                                              float* __restrict__ d_uh, float* __restrict__ d_v, int64_t Tn,
+                                                              int64_t S, int64_t H) {
+  __shared__ float DS[BTC][BJ];
+  const int64_t b = blockIdx.z, j0 = (int64_t)blockIdx.x * BJ, h = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  const bool h_ok = h < H;
+  float u[BJ], acc[BJ];
+#pragma unroll
+  for (int jj = 0; jj < BJ; ++jj) {
+    const int64_t j = j0 + jj;
+    u[jj] = (h_ok && j < S) ? Elem<T>::ld(uh + (b * S + j) * H + h) : 0.f;
+    acc[jj] = 0.f;
+  }
+  float dv = 0.f;
+  for (int64_t tc = 0; tc < Tn; tc += BTC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < BTC * BJ; e += 256) {
+      const int tt = e / BJ, jj = e % BJ;
+      const int64_t t = tc + tt, j = j0 + jj;
+      DS[tt][jj] = (t < Tn && j < S) ? ds[(b * Tn + t) * S + j] : 0.f;
+    }
+    __syncthreads();
+    const int tmax = (int)((Tn - tc) < BTC ? (Tn - tc) : BTC);
+    for (int tt = 0; tt < tmax; ++tt) {
+      const float w = h_ok ? wq[(b * Tn + tc + tt) * H + h] : 0.f;
+#pragma unroll
+      for (int jj = 0; jj < BJ; ++jj) {
+        const float th = tanh_t<FAST>(w + u[jj]);
+        const float g = DS[tt][jj];
+        acc[jj] += g * (1.f - th * th);
+        dv += g * th;
+      }
+    }
+  }
+  if (h_ok) {
+    const float vh = v[h];
+#pragma unroll
+    for (int jj = 0; jj < BJ; ++jj) {
+      const int64_t j = j0 + jj;
+      if (j < S) d_uh[(b * S + j) * H + h] = vh * acc[jj];
+    }
+    atomicAdd(d_v + h, dv);
+  }
+}
+
+// sweep 2: thread owns h, workgroup owns CT target rows; sums over all j.
+constexpr int CT = 8;
+constexpr int CJC = 64;  // j chunk staged in LDS
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __restrict__ ds, const float* __restrict__ wq,
+                                                              const T* __restrict__ uh, const float* __restrict__ v,
+                                                              float* __restrict__ d_wq, int64_t Tn, int64_t S, int64_t H) {
+  __shared__ float DS[CT][CJC];
+  const int64_t b = blockIdx.z, t0 = (int64_t)blockIdx.x * CT, h = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  const bool h_ok = h < H;
+  float w[CT], acc[CT];
+#pragma unroll
+  for (int tt = 0; tt < CT; ++tt) {
+    const int64_t t = t0 + tt;
+    w[tt] = (h_ok && t < Tn) ? wq[(b * Tn + t) * H + h] : 0.f;
+    acc[tt] = 0.f;
+  }
+  for (int64_t jc = 0; jc < S; jc += CJC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < CT * CJC; e += 256) {
+      const int tt = e / CJC, jj = e % CJC;
+      const int64_t t = t0 + tt, j = jc + jj;
+      DS[tt][jj] = (t < Tn && j < S) ? ds[(b * Tn + t) * S + j] : 0.f;
+    }
+    __syncthreads();
+    const int jmax = (int)((S - jc) < CJC ? (S - jc) : CJC);
+    for (int jj = 0; jj < jmax; ++jj) {
+      const float u = h_ok ? Elem<T>::ld(uh + (b * S + jc + jj) * H + h) : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < CT; ++tt) {
+        const float th = tanh_t<FAST>(w[tt] + u);
+        acc[tt] += DS[tt][jj] * (1.f - th * th);
+      }
+    }
+  }
+  if (h_ok) {
+    const float vh = v[h];
+#pragma unroll
+    for (int tt = 0; tt < CT; ++tt) {
+      const int64_t t = t0 + tt;
+      if (t < Tn) d_wq[(b * Tn + t) * H + h] = vh * acc[tt];
+    }
+  }
+}
+
+// ---- K11 ---------------------------------------------------------------------------------------
+__global__ void copy_scatter_fwd_kernel(const int64_t* __restrict__ src, const float* __restrict__ w,
+                                        float* __restrict__ dist, int64_t B, int64_t Tn, int64_t S, int64_t V) {
+  const int64_t n = B * Tn * S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t sidx = i % S, bt = i / S, b = bt / Tn;
+    const int64_t tok = src[b * S + sidx];
+    const float val = w[i];
+    if (tok >= 0 && tok < V && val != 0.f) atomicAdd(dist + bt * V + tok, val);
+  }
+}
+
+__global__ void copy_scatter_bwd_kernel(const int64_t* __restrict__ src, const float* __restrict__ d_dist,
+                                        float* __restrict__ d_w, int64_t B, int64_t Tn, int64_t S, int64_t V) {
+  const int64_t n = B * Tn * S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t sidx = i % S, bt = i / S, b = bt / Tn;
+    const int64_t tok = src[b * S + sidx];
+    d_w[i] = (tok >= 0 && tok < V) ? d_dist[bt * V + tok] : 0.f;
+  }
+}
+
+// ---- K12 / K13 ---------------------------------------------------------------------------------
+__global__ void nll_fwd_kernel(const float* __restrict__ dist, const int64_t* __restrict__ target,
+                               float* __restrict__ per_row, int64_t rows, int64_t V) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t y = target[r];
+    per_row[r] = (y > 0 && y < V) ? -logf(dist[r * V + y] + 1e-8f) : 0.f;
+  }
+}
+
+__global__ void nll_bwd_kernel(const float* __restrict__ dist, const int64_t* __restrict__ target,
+                               const float* __restrict__ g_row, float* __restrict__ d_dist, int64_t rows, int64_t V) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t y = target[r];
+    if (y > 0 && y < V) d_dist[r * V + y] = -g_row[r] / (dist[r * V + y] + 1e-8f);
+  }
+}
+
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ x, int64_t* __restrict__ idx,
+                                                         float* __restrict__ val, int64_t rows, int64_t cols, int64_t ld) {
+  __shared__ float sv[4];
+  __shared__ int64_t si[4];
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    float best = -INFINITY;
+    int64_t bi = cols;  // sentinel larger than any index so the lowest index wins ties
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+      const float vv = x[r * ld + c];
+      if (vv > best || (vv == best && c < bi)) {
+        best = vv;
+        bi = c;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int64_t oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      sv[threadIdx.x >> 6] = best;
+      si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+          best = sv[w];
+          bi = si[w];
+        }
+      idx[r] = bi < cols ? bi : 0;
+      if (val) val[r] = best;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int case_additive_scores_fwd(const float* wq, const void* uh, const float* v, float* s, int64_t B, int64_t T,
+                                        int64_t S, int64_t H, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(wq && uh && v && s && B > 0 && T > 0 && S > 0 && H > 0 && B < 65536, "case_additive_scores_fwd: bad argument");
+  const dim3 grid((unsigned)((S + AJ - 1) / AJ), (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CASE_F32)
+    hipLaunchKernelGGL((additive_fwd_kernel<float, false>), grid, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
+  else
+    hipLaunchKernelGGL((additive_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
+  return case_check_launch("case_additive_scores_fwd");
+}
+
+extern "C" int case_additive_scores_bwd(const float* ds, const float* wq, const void* uh, const float* v, float* d_wq,
+                                        float* d_uh, float* d_v, int64_t B, int64_t T, int64_t S, int64_t H, int32_t dtype,
+                                        case_stream_t stream) {
+  CASE_REQUIRE(ds && wq && uh && v && d_wq && d_uh && d_v && B > 0 && T > 0 && S > 0 && H > 0 && B < 65536,
+               "case_additive_scores_bwd: bad argument");
+  const unsigned hb = (unsigned)((H + 255) / 256);
+  const dim3 g1((unsigned)((S + BJ - 1) / BJ), hb, (unsigned)B), g2((unsigned)((T + CT - 1) / CT), hb, (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CASE_F32) {
+    hipLaunchKernelGGL((additive_bwd_uh_kernel<float, false>), g1, dim3(256), 0, st, ds, wq, (const float*)uh, v, d_uh, d_v, T, S, H);
+    hipLaunchKernelGGL((additive_bwd_wq_kernel<float, false>), g2, dim3(256), 0, st, ds, wq, (const float*)uh, v, d_wq, T, S, H);
+  } else {
+    hipLaunchKernelGGL((additive_bwd_uh_kernel<bf16_t, true>), g1, dim3(256), 0, st, ds, wq, (const bf16_t*)uh, v, d_uh, d_v, T, S, H);
+    hipLaunchKernelGGL((additive_bwd_wq_kernel<bf16_t, true>), g2, dim3(256), 0, st, ds, wq, (const bf16_t*)uh, v, d_wq, T, S, H);
+  }
+  return case_check_launch("case_additive_scores_bwd");
+}
+
+extern "C" int case_copy_scatter_fwd(const int64_t* src, const float* w, float* dist, int64_t B, int64_t T, int64_t S,
+                                     int64_t V, case_stream_t stream) {
+  CASE_REQUIRE(src && w && dist && B > 0 && T > 0 && S > 0 && V > 0, "case_copy_scatter_fwd: bad argument");
+  hipLaunchKernelGGL(copy_scatter_fwd_kernel, dim3(grid_for(B * T * S, 256, 2)), dim3(256), 0, (hipStream_t)stream, src, w,
+                     dist, B, T, S, V);
+  return case_check_launch("case_copy_scatter_fwd");
+}
+
+extern "C" int case_copy_scatter_bwd(const int64_t* src, const float* d_dist, float* d_w, int64_t B, int64_t T, int64_t S,
+                                     int64_t V, case_stream_t stream) {
+  CASE_REQUIRE(src && d_dist && d_w && B > 0 && T > 0 && S > 0 && V > 0, "case_copy_scatter_bwd: bad argument");
+  hipLaunchKernelGGL(copy_scatter_bwd_kernel, dim3(grid_for(B * T * S, 256, 2)), dim3(256), 0, (hipStream_t)stream, src,
+                     d_dist, d_w, B, T, S, V);
+  return case_check_launch("case_copy_scatter_bwd");
+}
+
+extern "C" int case_nll_gather_fwd(const float* dist, const int64_t* target, float* per_row, int64_t rows, int64_t V,
+                                   case_stream_t stream) {
+  CASE_REQUIRE(dist && target && per_row && rows > 0 && V > 0, "case_nll_gather_fwd: bad argument");
+  hipLaunchKernelGGL(nll_fwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, dist, target, per_row, rows, V);
+  return case_check_launch("case_nll_gather_fwd");
+}
+
+extern "C" int case_nll_gather_bwd(const float* dist, const int64_t* target, const float* g_row, float* d_dist,
+                                   int64_t rows, int64_t V, case_stream_t stream) {
+  CASE_REQUIRE(dist && target && g_row && d_dist && rows > 0 && V > 0, "case_nll_gather_bwd: bad argument");
+  hipLaunchKernelGGL(nll_bwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, dist, target, g_row, d_dist, rows, V);
+  return case_check_launch("case_nll_gather_bwd");
+}
+
+extern "C" int case_row_argmax(const float* x, int64_t* idx, float* val, int64_t rows, int64_t cols, int64_t ld,
+                               case_stream_t stream) {
+  CASE_REQUIRE(x && idx && rows > 0 && cols > 0 && ld >= cols, "case_row_argmax: bad argument");
+  hipLaunchKernelGGL(row_argmax_kernel, dim3(grid_for(rows, 1)), dim3(256), 0, (hipStream_t)stream, x, idx, val, rows, cols, ld);
+  return case_check_launch("case_row_argmax");
+}

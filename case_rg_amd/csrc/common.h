@@ -1,0 +1,91 @@
+// Shared device helpers for libcase_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "case_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+int case_set_error(int code, const char* fmt, ...);
+int case_check_launch(const char* what);
+
+#define CASE_REQUIRE(cond, ...)                          \
+  do {                                                   \
+    if (!(cond)) return case_set_error(CASE_E_ARG, __VA_ARGS__); \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide reductions for <= 1024 threads; `red` is a 32-float LDS scratch
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = (lane < nw) ? red[lane] : 0.f;
+  t = wave_sum(t);
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = (lane < nw) ? red[lane] : -INFINITY;
+  t = wave_max(t);
+  return t;
+}
+
+// Counter-based RNG (splitmix64 finaliser over seed/offset/index): uniform in [0,1).
+// Keyed by element index so forward and backward regenerate the same keep mask.
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int grid_for(int64_t n, int block, int per_thread = 1, int cap = 256 * 8) {
+  int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}

@@ -1,0 +1,405 @@
+// HBM-bound elementwise / gather / small-reduction kernels: K1 embed+pos, K9 masked mean, Interaction
+// feature assembly (K8 epilogue), Highway gate (K14 epilogue), residual add, dropout, row masking,
+// bias-gradient column sums and dtype casts.  Grid-stride, consecutive lanes on consecutive addresses.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(o + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed,
+                               uint64_t offset) {
+  const float scale = 1.f / (1.f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(y + i, rng_uniform(seed, offset + (uint64_t)i) >= p ? Elem<T>::ld(x + i) * scale : 0.f);
+}
+
+template <typename T>
+__global__ void mask_rows_kernel(const T* __restrict__ x, const uint8_t* __restrict__ valid, T* __restrict__ y,
+                                 int64_t rows, int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(y + i, valid[i / cols] ? Elem<T>::ld(x + i) : 0.f);
+}
+
+// column sums: workgroup = 64 columns x 4 row-lanes; each workgroup walks a strided slice of the rows
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                     int64_t cols, int row_splits) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t col = (int64_t)(blockIdx.x / row_splits) * 64 + cx;
+  const int split = blockIdx.x % row_splits;
+  float s = 0.f;
+  if (col < cols)
+    for (int64_t r = (int64_t)split * 4 + ry; r < rows; r += (int64_t)row_splits * 4) s += Elem<T>::ld(x + r * cols + col);
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) atomicAdd(out + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ x, TD* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<TD>::st(y + i, Elem<TS>::ld(x + i));
+}
+
+template <typename T>
+__global__ void scale_cols_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int64_t rows,
+                                  int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(y + i, Elem<T>::ld(x + i) * w[i % cols]);
+}
+
+// dx = dy * w ; dw[c] += sum_r dy * x   (same tiling as colsum)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cols_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ w, T* __restrict__ dx,
+                                                             float* __restrict__ dw, int64_t rows, int64_t cols,
+                                                             int row_splits) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t col = (int64_t)(blockIdx.x / row_splits) * 64 + cx;
+  const int split = blockIdx.x % row_splits;
+  float s = 0.f;
+  if (col < cols) {
+    const float wc = w[col];
+    for (int64_t r = (int64_t)split * 4 + ry; r < rows; r += (int64_t)row_splits * 4) {
+      const float g = Elem<T>::ld(dy + r * cols + col);
+      s += g * Elem<T>::ld(x + r * cols + col);
+      Elem<T>::st(dx + r * cols + col, g * wc);
+    }
+  }
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) atomicAdd(dw + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+}
+
+// y[r, :] = x[r, :] * scale + (pe ? pe[r % seq_len, :] : 0)   (stand-alone PositionalEmbedding and its backward)
+template <typename T>
+__global__ void scale_add_rows_kernel(const T* __restrict__ x, const float* __restrict__ pe, T* __restrict__ y,
+                                      int64_t rows, int64_t seq_len, int64_t H, float scale) {
+  const int64_t n = rows * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H, c = i % H;
+    Elem<T>::st(y + i, Elem<T>::ld(x + i) * scale + (pe ? pe[(r % seq_len) * H + c] : 0.f));
+  }
+}
+
+// ---- K1 ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_pos_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                     const float* __restrict__ pe, T* __restrict__ out, int64_t rows, int64_t seq_len,
+                                     int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset) {
+  const int64_t n = rows * H;
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H, c = i % H;
+    int64_t id = ids[r];
+    if (id < 0 || id >= vocab) id = 0;  // out-of-range ids read the padding row instead of faulting
+    float v = table[id * H + c] * scale + pe[(r % seq_len) * H + c];
+    if (drop_p > 0.f) v = rng_uniform(seed, offset + (uint64_t)i) >= drop_p ? v * ks : 0.f;
+    Elem<T>::st(out + i, v);
+  }
+}
+
+template <typename T>
+__global__ void embed_pos_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d_out,
+                                     float* __restrict__ d_table, int64_t rows, int64_t H, int64_t vocab, float scale,
+                                     float drop_p, uint64_t seed, uint64_t offset) {
+  const int64_t n = rows * H;
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H, c = i % H;
+    const int64_t id = ids[r];
+    if (id <= 0 || id >= vocab) continue;  // padding_idx = 0 gets no gradient
+    float g = Elem<T>::ld(d_out + i);
+    if (drop_p > 0.f) g = rng_uniform(seed, offset + (uint64_t)i) >= drop_p ? g * ks : 0.f;
+    atomicAdd(d_table + id * H + c, g * scale);
+  }
+}
+
+// ---- K9 ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void masked_mean_fwd_kernel(const T* __restrict__ x, const uint8_t* __restrict__ valid, T* __restrict__ out,
+                                       int64_t n, int64_t L, int64_t H) {
+  const int64_t total = n * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i / H, c = i % H;
+    float acc = 0.f, cnt = 0.f;
+    for (int64_t l = 0; l < L; ++l)
+      if (valid[s * L + l]) {
+        acc += Elem<T>::ld(x + (s * L + l) * H + c);
+        cnt += 1.f;
+      }
+    Elem<T>::st(out + i, acc / cnt);
+  }
+}
+
+template <typename T>
+__global__ void masked_mean_bwd_kernel(const T* __restrict__ d_out, const uint8_t* __restrict__ valid,
+                                       T* __restrict__ dx, int64_t n, int64_t L, int64_t H) {
+  const int64_t total = n * L * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i % H, sl = i / H, s = sl / L;
+    float cnt = 0.f;
+    for (int64_t l = 0; l < L; ++l) cnt += valid[s * L + l] ? 1.f : 0.f;
+    Elem<T>::st(dx + i, valid[sl] ? Elem<T>::ld(d_out + s * H + c) / cnt : 0.f);
+  }
+}
+
+// ---- K14 epilogue ------------------------------------------------------------------------------
+template <typename T>
+__global__ void highway_fwd_kernel(const T* __restrict__ gnl, T* __restrict__ y, int64_t rows, int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    const T* p = gnl + r * 3 * cols + c;
+    const float t = 1.f / (1.f + expf(-Elem<T>::ld(p)));
+    Elem<T>::st(y + i, t * tanhf(Elem<T>::ld(p + cols)) + (1.f - t) * Elem<T>::ld(p + 2 * cols));
+  }
+}
+
+template <typename T>
+__global__ void highway_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ gnl, T* __restrict__ d_gnl,
+                                   int64_t rows, int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    const T* p = gnl + r * 3 * cols + c;
+    T* q = d_gnl + r * 3 * cols + c;
+    const float t = 1.f / (1.f + expf(-Elem<T>::ld(p)));
+    const float f = tanhf(Elem<T>::ld(p + cols)), lin = Elem<T>::ld(p + 2 * cols), g = Elem<T>::ld(dy + i);
+    Elem<T>::st(q, g * (f - lin) * t * (1.f - t));
+    Elem<T>::st(q + cols, g * t * (1.f - f * f));
+    Elem<T>::st(q + 2 * cols, g * (1.f - t));
+  }
+}
+
+// ---- K8 feature assembly -----------------------------------------------------------------------
+template <typename T>
+__global__ void concat5_fwd_kernel(const T* __restrict__ e, const T* __restrict__ a1, const T* __restrict__ a2,
+                                   const uint8_t* __restrict__ valid, T* __restrict__ out, int64_t rows, int64_t H) {
+  const int64_t n = rows * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H, c = i % H;
+    const bool ok = valid[r];
+    const float ev = ok ? Elem<T>::ld(e + i) : 0.f, x1 = ok ? Elem<T>::ld(a1 + i) : 0.f, x2 = ok ? Elem<T>::ld(a2 + i) : 0.f;
+    T* o = out + r * 5 * H + c;
+    Elem<T>::st(o, ev);
+    Elem<T>::st(o + H, x1);
+    Elem<T>::st(o + 2 * H, x2);
+    Elem<T>::st(o + 3 * H, ev * x1);
+    Elem<T>::st(o + 4 * H, ev * x2);
+  }
+}
+
+template <typename T>
+__global__ void concat5_bwd_kernel(const T* __restrict__ d_out, const T* __restrict__ e, const T* __restrict__ a1,
+                                   const T* __restrict__ a2, const uint8_t* __restrict__ valid, T* __restrict__ de,
+                                   T* __restrict__ da1, T* __restrict__ da2, int64_t rows, int64_t H) {
+  const int64_t n = rows * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H, c = i % H;
+    float ge = 0.f, g1 = 0.f, g2 = 0.f;
+    if (valid[r]) {
+      const T* g = d_out + r * 5 * H + c;
+      const float ev = Elem<T>::ld(e + i), x1 = Elem<T>::ld(a1 + i), x2 = Elem<T>::ld(a2 + i);
+      const float g3 = Elem<T>::ld(g + 3 * H), g4 = Elem<T>::ld(g + 4 * H);
+      ge = Elem<T>::ld(g) + g3 * x1 + g4 * x2;
+      g1 = Elem<T>::ld(g + H) + g3 * ev;
+      g2 = Elem<T>::ld(g + 2 * H) + g4 * ev;
+    }
+    Elem<T>::st(de + i, ge);
+    Elem<T>::st(da1 + i, g1);
+    Elem<T>::st(da2 + i, g2);
+  }
+}
+
+template <typename T>
+__global__ void max_over_p_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int32_t* __restrict__ arg, int64_t B,
+                                      int64_t P, int64_t inner) {
+  const int64_t n = B * inner;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / inner, k = i % inner;
+    float best = Elem<T>::ld(x + (b * P) * inner + k);
+    int32_t bi = 0;
+    for (int64_t p = 1; p < P; ++p) {
+      const float v = Elem<T>::ld(x + (b * P + p) * inner + k);
+      if (v > best) {  // first maximum wins, as torch.max
+        best = v;
+        bi = (int32_t)p;
+      }
+    }
+    Elem<T>::st(out + i, best);
+    arg[i] = bi;
+  }
+}
+
+template <typename T>
+__global__ void max_over_p_bwd_kernel(const T* __restrict__ d_out, const int32_t* __restrict__ arg, T* __restrict__ dx,
+                                      int64_t B, int64_t P, int64_t inner) {
+  const int64_t n = B * P * inner;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i % inner, bp = i / inner, b = bp / P, p = bp % P;
+    Elem<T>::st(dx + i, arg[b * inner + k] == (int32_t)p ? Elem<T>::ld(d_out + b * inner + k) : 0.f);
+  }
+}
+
+}  // namespace
+
+#define EW_DISPATCH(what, n_elems, KERNEL, ...)                                                              \
+  do {                                                                                                       \
+    const int grid = grid_for((n_elems), EW_THREADS, 4);                                                     \
+    hipStream_t s_ = (hipStream_t)stream;                                                                    \
+    if (dtype == CASE_F32) { typedef float T; hipLaunchKernelGGL(KERNEL<T>, dim3(grid), dim3(EW_THREADS), 0, s_, __VA_ARGS__); } \
+    else if (dtype == CASE_BF16) { typedef bf16_t T; hipLaunchKernelGGL(KERNEL<T>, dim3(grid), dim3(EW_THREADS), 0, s_, __VA_ARGS__); } \
+    else return case_set_error(CASE_E_UNSUPPORTED, what ": dtype %d", dtype);                              \
+    return case_check_launch(what);                                                                          \
+  } while (0)
+
+extern "C" int case_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(a && b && out && n > 0, "case_add: bad argument");
+  EW_DISPATCH("case_add", n, add_kernel, (const T*)a, (const T*)b, (T*)out, n);
+}
+
+extern "C" int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,
+                            case_stream_t stream) {
+  CASE_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "case_dropout: bad argument");
+  EW_DISPATCH("case_dropout", n, dropout_kernel, (const T*)x, (T*)y, n, p, seed, offset);
+}
+
+extern "C" int case_mask_rows(const void* x, const uint8_t* row_valid, void* y, int64_t rows, int64_t cols,
+                              int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(x && row_valid && y && rows > 0 && cols > 0, "case_mask_rows: bad argument");
+  EW_DISPATCH("case_mask_rows", rows * cols, mask_rows_kernel, (const T*)x, row_valid, (T*)y, rows, cols);
+}
+
+static int colsum_splits(int64_t rows, int64_t cols) {
+  const int64_t col_blocks = (cols + 63) / 64;
+  int64_t want = 2048 / col_blocks;  // aim at ~2048 workgroups
+  const int64_t cap = (rows + 31) / 32;
+  if (want > cap) want = cap;
+  return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int case_colsum(const void* x, float* out, int64_t rows, int64_t cols, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(x && out && rows > 0 && cols > 0, "case_colsum: bad argument");
+  const int splits = colsum_splits(rows, cols);
+  const int grid = (int)((cols + 63) / 64) * splits;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, out, rows, cols, splits);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, out, rows, cols, splits);
+  return case_check_launch("case_colsum");
+}
+
+extern "C" int case_cast(const void* x, void* y, int64_t n, int32_t src, int32_t dst, case_stream_t stream) {
+  CASE_REQUIRE(x && y && n > 0, "case_cast: bad argument");
+  const int grid = grid_for(n, EW_THREADS, 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (src == CASE_F32 && dst == CASE_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(EW_THREADS), 0, s, (const float*)x, (bf16_t*)y, n);
+  else if (src == CASE_BF16 && dst == CASE_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(EW_THREADS), 0, s, (const bf16_t*)x, (float*)y, n);
+  else if (src == CASE_F32 && dst == CASE_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(EW_THREADS), 0, s, (const float*)x, (float*)y, n);
+  else if (src == CASE_BF16 && dst == CASE_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(EW_THREADS), 0, s, (const bf16_t*)x, (bf16_t*)y, n);
+  else return case_set_error(CASE_E_UNSUPPORTED, "case_cast: dtype");
+  return case_check_launch("case_cast");
+}
+
+extern "C" int case_scale_cols(const void* x, const float* w, void* y, int64_t rows, int64_t cols, int32_t dtype,
+                               case_stream_t stream) {
+  CASE_REQUIRE(x && w && y && rows > 0 && cols > 0, "case_scale_cols: bad argument");
+  EW_DISPATCH("case_scale_cols", rows * cols, scale_cols_kernel, (const T*)x, w, (T*)y, rows, cols);
+}
+
+extern "C" int case_scale_cols_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int64_t rows,
+                                   int64_t cols, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(dy && x && w && dx && dw && rows > 0 && cols > 0, "case_scale_cols_bwd: bad argument");
+  // every row must be visited exactly once for dx: one split per 4-row lane group is required
+  const int splits = colsum_splits(rows, cols);
+  const int grid = (int)((cols + 63) / 64) * splits;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32) hipLaunchKernelGGL(scale_cols_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, w, (float*)dx, dw, rows, cols, splits);
+  else hipLaunchKernelGGL(scale_cols_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, (bf16_t*)dx, dw, rows, cols, splits);
+  return case_check_launch("case_scale_cols_bwd");
+}
+
+extern "C" int case_scale_add_rows(const void* x, const float* pe, void* y, int64_t rows, int64_t seq_len, int64_t H,
+                                   float scale, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(x && y && rows > 0 && seq_len > 0 && H > 0, "case_scale_add_rows: bad argument");
+  EW_DISPATCH("case_scale_add_rows", rows * H, scale_add_rows_kernel, (const T*)x, pe, (T*)y, rows, seq_len, H, scale);
+}
+
+extern "C" int case_embed_pos_fwd(const int64_t* ids, const float* table, const float* pe, void* out, int64_t rows,
+                                  int64_t seq_len, int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed,
+                                  uint64_t offset, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(ids && table && pe && out && rows > 0 && seq_len > 0 && H > 0 && vocab > 0, "case_embed_pos_fwd: bad argument");
+  EW_DISPATCH("case_embed_pos_fwd", rows * H, embed_pos_fwd_kernel, ids, table, pe, (T*)out, rows, seq_len, H, vocab, scale,
+              drop_p, seed, offset);
+}
+
+extern "C" int case_embed_pos_bwd(const int64_t* ids, const void* d_out, float* d_table, int64_t rows, int64_t H,
+                                  int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
+                                  case_stream_t stream) {
+  CASE_REQUIRE(ids && d_out && d_table && rows > 0 && H > 0 && vocab > 0, "case_embed_pos_bwd: bad argument");
+  EW_DISPATCH("case_embed_pos_bwd", rows * H, embed_pos_bwd_kernel, ids, (const T*)d_out, d_table, rows, H, vocab, scale,
+              drop_p, seed, offset);
+}
+
+extern "C" int case_masked_mean_fwd(const void* x, const uint8_t* valid, void* out, int64_t n, int64_t L, int64_t H,
+                                    int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(x && valid && out && n > 0 && L > 0 && H > 0, "case_masked_mean_fwd: bad argument");
+  EW_DISPATCH("case_masked_mean_fwd", n * H, masked_mean_fwd_kernel, (const T*)x, valid, (T*)out, n, L, H);
+}
+
+extern "C" int case_masked_mean_bwd(const void* d_out, const uint8_t* valid, void* dx, int64_t n, int64_t L, int64_t H,
+                                    int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(d_out && valid && dx && n > 0 && L > 0 && H > 0, "case_masked_mean_bwd: bad argument");
+  EW_DISPATCH("case_masked_mean_bwd", n * L * H, masked_mean_bwd_kernel, (const T*)d_out, valid, (T*)dx, n, L, H);
+}
+
+extern "C" int case_highway_gate_fwd(const void* gnl, void* y, int64_t rows, int64_t cols, int32_t dtype,
+                                     case_stream_t stream) {
+  CASE_REQUIRE(gnl && y && rows > 0 && cols > 0, "case_highway_gate_fwd: bad argument");
+  EW_DISPATCH("case_highway_gate_fwd", rows * cols, highway_fwd_kernel, (const T*)gnl, (T*)y, rows, cols);
+}
+
+extern "C" int case_highway_gate_bwd(const void* dy, const void* gnl, void* d_gnl, int64_t rows, int64_t cols,
+                                     int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(dy && gnl && d_gnl && rows > 0 && cols > 0, "case_highway_gate_bwd: bad argument");
+  EW_DISPATCH("case_highway_gate_bwd", rows * cols, highway_bwd_kernel, (const T*)dy, (const T*)gnl, (T*)d_gnl, rows, cols);
+}
+
+extern "C" int case_concat5_fwd(const void* e, const void* a1, const void* a2, const uint8_t* row_valid, void* out,
+                                int64_t rows, int64_t H, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(e && a1 && a2 && row_valid && out && rows > 0 && H > 0, "case_concat5_fwd: bad argument");
+  EW_DISPATCH("case_concat5_fwd", rows * H, concat5_fwd_kernel, (const T*)e, (const T*)a1, (const T*)a2, row_valid, (T*)out,
+              rows, H);
+}
+
+extern "C" int case_concat5_bwd(const void* d_out, const void* e, const void* a1, const void* a2,
+                                const uint8_t* row_valid, void* de, void* da1, void* da2, int64_t rows, int64_t H,
+                                int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(d_out && e && a1 && a2 && row_valid && de && da1 && da2 && rows > 0 && H > 0, "case_concat5_bwd: bad argument");
+  EW_DISPATCH("case_concat5_bwd", rows * H, concat5_bwd_kernel, (const T*)d_out, (const T*)e, (const T*)a1, (const T*)a2,
+              row_valid, (T*)de, (T*)da1, (T*)da2, rows, H);
+}
+
+extern "C" int case_max_over_p_fwd(const void* x, void* out, int32_t* argmax, int64_t B, int64_t P, int64_t inner,
+                                   int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(x && out && argmax && B > 0 && P > 0 && inner > 0, "case_max_over_p_fwd: bad argument");
+  EW_DISPATCH("case_max_over_p_fwd", B * inner, max_over_p_fwd_kernel, (const T*)x, (T*)out, argmax, B, P, inner);
+}
+
+extern "C" int case_max_over_p_bwd(const void* d_out, const int32_t* argmax, void* dx, int64_t B, int64_t P,
+                                   int64_t inner, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(d_out && argmax && dx && B > 0 && P > 0 && inner > 0, "case_max_over_p_bwd: bad argument");
+  EW_DISPATCH("case_max_over_p_bwd", B * P * inner, max_over_p_bwd_kernel, (const T*)d_out, argmax, (T*)dx, B, P, inner);
+}

@@ -1,0 +1,253 @@
+// K2 LayerNorm and the masked row softmax (softmax stage of K4/K5/K6 and of K7/K8/K10/K11).
+// HBM-bound row kernels: one wave (C <= 1024) or one 256-thread workgroup per row, grid-stride over rows,
+// wavefront shuffles for the reductions, f32 statistics regardless of the storage dtype.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_MAXPT = 16;  // columns per thread cached in registers by the backward (cols <= 4096)
+
+template <typename T>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ x2,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int64_t rows, int64_t cols, float eps) {
+  __shared__ float red[32];
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T* xr = x + r * cols;
+    const T* x2r = x2 ? x2 + r * cols : nullptr;
+    float s = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += LN_THREADS) s += Elem<T>::ld(xr + c) + (x2r ? Elem<T>::ld(x2r + c) : 0.f);
+    const float mu = block_sum(s, red) / (float)cols;
+    float q = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += LN_THREADS) {
+      const float d = Elem<T>::ld(xr + c) + (x2r ? Elem<T>::ld(x2r + c) : 0.f) - mu;
+      q += d * d;
+    }
+    const float rs = rsqrtf(block_sum(q, red) / (float)cols + eps);
+    if (threadIdx.x == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+    T* yr = y + r * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += LN_THREADS) {
+      const float v = Elem<T>::ld(xr + c) + (x2r ? Elem<T>::ld(x2r + c) : 0.f);
+      Elem<T>::st(yr + c, (v - mu) * rs * gamma[c] + beta[c]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ x2, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta,
+                                                            int64_t rows, int64_t cols) {
+  __shared__ float red[32];
+  float acc_g[LN_MAXPT], acc_b[LN_MAXPT];
+#pragma unroll
+  for (int i = 0; i < LN_MAXPT; ++i) acc_g[i] = acc_b[i] = 0.f;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T* xr = x + r * cols;
+    const T* x2r = x2 ? x2 + r * cols : nullptr;
+    const T* dyr = dy + r * cols;
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPT; ++i) {
+      const int64_t c = threadIdx.x + (int64_t)i * LN_THREADS;
+      if (c < cols) {
+        const float xh = (Elem<T>::ld(xr + c) + (x2r ? Elem<T>::ld(x2r + c) : 0.f) - mu) * rs;
+        const float d = Elem<T>::ld(dyr + c);
+        const float g = d * gamma[c];
+        s1 += g;
+        s2 += g * xh;
+        acc_g[i] += d * xh;
+        acc_b[i] += d;
+      }
+    }
+    const float m1 = block_sum(s1, red) / (float)cols;
+    const float m2 = block_sum(s2, red) / (float)cols;
+    T* dxr = dx + r * cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPT; ++i) {
+      const int64_t c = threadIdx.x + (int64_t)i * LN_THREADS;
+      if (c < cols) {
+        const float xh = (Elem<T>::ld(xr + c) + (x2r ? Elem<T>::ld(x2r + c) : 0.f) - mu) * rs;
+        const float g = Elem<T>::ld(dyr + c) * gamma[c];
+        Elem<T>::st(dxr + c, rs * (g - m1 - xh * m2));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXPT; ++i) {
+    const int64_t c = threadIdx.x + (int64_t)i * LN_THREADS;
+    if (c < cols) {
+      atomicAdd(d_gamma + c, acc_g[i]);
+      atomicAdd(d_beta + c, acc_b[i]);
+    }
+  }
+}
+
+// ---- softmax ----------------------------------------------------------------------------------
+template <int TPR>  // threads per row: 64 (wave) or 256 (workgroup)
+__device__ __forceinline__ float row_max(float v, float* red) {
+  if constexpr (TPR == 64) return wave_max(v);
+  else return block_max(v, red);
+}
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float* red) {
+  if constexpr (TPR == 64) return wave_sum(v);
+  else return block_sum(v, red);
+}
+
+template <typename TI, typename TO, int TPR>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const CaseSoftmaxDesc d, const TI* __restrict__ x,
+                                                          const uint8_t* __restrict__ col_valid,
+                                                          const uint8_t* __restrict__ row_valid, TO* __restrict__ p_out,
+                                                          TO* __restrict__ y_out) {
+  __shared__ float red[32];
+  const int rows_per_block = 256 / TPR;
+  const int sub = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int64_t total = d.outer * d.inner * d.R;
+  const float keep_scale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+  for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < total; base += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t row = base + sub;
+    const bool live = row < total;  // keep every wave in the block-level reductions
+    const int64_t rr = live ? row : 0;
+    const int64_t r = rr % d.R, o = rr / (d.R * d.inner);
+    const TI* xr = x + rr * d.C;
+    const uint8_t* cv = col_valid ? col_valid + o * d.C : nullptr;
+    const bool row_ok = live && (!row_valid || row_valid[o * d.R + r]);
+    const int64_t cmax = d.causal ? (r + 1 < d.C ? r + 1 : d.C) : d.C;
+    float m = -INFINITY;
+    if (row_ok)
+      for (int64_t c = t; c < cmax; c += TPR)
+        if (!cv || cv[c]) m = fmaxf(m, Elem<TI>::ld(xr + c));
+    m = row_max<TPR>(m, red);
+    float s = 0.f;
+    if (row_ok && m > -INFINITY)
+      for (int64_t c = t; c < cmax; c += TPR)
+        if (!cv || cv[c]) s += expf(Elem<TI>::ld(xr + c) - m);
+    s = row_sum<TPR>(s, red);
+    if (!live) continue;
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    for (int64_t c = t; c < d.C; c += TPR) {
+      float p = 0.f;
+      if (row_ok && c < cmax && (!cv || cv[c]) && inv > 0.f) p = expf(Elem<TI>::ld(xr + c) - m) * inv;
+      Elem<TO>::st(p_out + rr * d.C + c, p);
+      if (d.drop_p > 0.f) {
+        const float u = rng_uniform(d.seed, d.offset + (uint64_t)(rr * d.C + c));
+        Elem<TO>::st(y_out + rr * d.C + c, u >= d.drop_p ? p * keep_scale : 0.f);
+      }
+    }
+  }
+}
+
+template <typename TI, typename TO, int TPR>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const CaseSoftmaxDesc d, const TO* __restrict__ dy,
+                                                          const TO* __restrict__ p, TI* __restrict__ dx) {
+  __shared__ float red[32];
+  const int rows_per_block = 256 / TPR;
+  const int sub = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int64_t total = d.outer * d.inner * d.R;
+  const float keep_scale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+  for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < total; base += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t row = base + sub;
+    const bool live = row < total;
+    const int64_t rr = live ? row : 0;
+    float dot = 0.f;
+    if (live)
+      for (int64_t c = t; c < d.C; c += TPR) {
+        float g = Elem<TO>::ld(dy + rr * d.C + c);
+        if (d.drop_p > 0.f) g = rng_uniform(d.seed, d.offset + (uint64_t)(rr * d.C + c)) >= d.drop_p ? g * keep_scale : 0.f;
+        dot += g * Elem<TO>::ld(p + rr * d.C + c);
+      }
+    dot = row_sum<TPR>(dot, red);
+    if (!live) continue;
+    for (int64_t c = t; c < d.C; c += TPR) {
+      float g = Elem<TO>::ld(dy + rr * d.C + c);
+      if (d.drop_p > 0.f) g = rng_uniform(d.seed, d.offset + (uint64_t)(rr * d.C + c)) >= d.drop_p ? g * keep_scale : 0.f;
+      const float pv = Elem<TO>::ld(p + rr * d.C + c);
+      Elem<TI>::st(dx + rr * d.C + c, pv * (g - dot));
+    }
+  }
+}
+
+template <typename TI, typename TO>
+int softmax_launch(const CaseSoftmaxDesc* d, bool fwd, const void* a, const uint8_t* cv, const uint8_t* rv, void* b,
+                   void* c, hipStream_t s) {
+  const int64_t total = d->outer * d->inner * d->R;
+  if (d->C <= 1024) {
+    const int grid = grid_for(total, 4, 1, 256 * 16);
+    if (fwd) hipLaunchKernelGGL((softmax_fwd_kernel<TI, TO, 64>), dim3(grid), dim3(256), 0, s, *d, (const TI*)a, cv, rv, (TO*)b, (TO*)c);
+    else hipLaunchKernelGGL((softmax_bwd_kernel<TI, TO, 64>), dim3(grid), dim3(256), 0, s, *d, (const TO*)a, (const TO*)b, (TI*)c);
+  } else {
+    const int grid = grid_for(total, 1, 1, 256 * 8);
+    if (fwd) hipLaunchKernelGGL((softmax_fwd_kernel<TI, TO, 256>), dim3(grid), dim3(256), 0, s, *d, (const TI*)a, cv, rv, (TO*)b, (TO*)c);
+    else hipLaunchKernelGGL((softmax_bwd_kernel<TI, TO, 256>), dim3(grid), dim3(256), 0, s, *d, (const TO*)a, (const TO*)b, (TI*)c);
+  }
+  return case_check_launch(fwd ? "case_softmax_fwd" : "case_softmax_bwd");
+}
+
+template <bool FWD>
+int softmax_dispatch(const CaseSoftmaxDesc* d, const void* a, const uint8_t* cv, const uint8_t* rv, void* b, void* c,
+                     hipStream_t s) {
+  const int i = d->in_dtype, o = d->out_dtype;
+  if (i == CASE_F32 && o == CASE_F32) return softmax_launch<float, float>(d, FWD, a, cv, rv, b, c, s);
+  if (i == CASE_BF16 && o == CASE_BF16) return softmax_launch<bf16_t, bf16_t>(d, FWD, a, cv, rv, b, c, s);
+  if (i == CASE_BF16 && o == CASE_F32) return softmax_launch<bf16_t, float>(d, FWD, a, cv, rv, b, c, s);
+  if (i == CASE_F32 && o == CASE_BF16) return softmax_launch<float, bf16_t>(d, FWD, a, cv, rv, b, c, s);
+  return case_set_error(CASE_E_UNSUPPORTED, "case_softmax: dtype combination");
+}
+
+}  // namespace
+
+extern "C" int case_layernorm_fwd(const void* x, const void* x2, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype,
+                                  case_stream_t stream) {
+  CASE_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && cols > 0, "case_layernorm_fwd: bad argument");
+  const int grid = grid_for(rows, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(LN_THREADS), 0, s, (const float*)x, (const float*)x2, gamma,
+                       beta, (float*)y, mean, rstd, rows, cols, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)x, (const bf16_t*)x2,
+                       gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps);
+  return case_check_launch("case_layernorm_fwd");
+}
+
+extern "C" int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
+                                  const float* rstd, void* dx, float* d_gamma, float* d_beta, int64_t rows, int64_t cols,
+                                  int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(dy && x && gamma && mean && rstd && dx && d_gamma && d_beta && rows > 0 && cols > 0,
+               "case_layernorm_bwd: bad argument");
+  CASE_REQUIRE(cols <= (int64_t)LN_THREADS * LN_MAXPT, "case_layernorm_bwd: cols %lld > %d", (long long)cols,
+               LN_THREADS * LN_MAXPT);
+  const int grid = grid_for(rows, 1, 8, 256 * 2);  // few workgroups -> few atomics on d_gamma / d_beta
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(LN_THREADS), 0, s, (const float*)dy, (const float*)x,
+                       (const float*)x2, gamma, mean, rstd, (float*)dx, d_gamma, d_beta, rows, cols);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)x2, gamma, mean, rstd, (bf16_t*)dx, d_gamma, d_beta, rows, cols);
+  return case_check_launch("case_layernorm_bwd");
+}
+
+extern "C" int case_softmax_fwd(const CaseSoftmaxDesc* d, const void* x, const uint8_t* col_valid,
+                                const uint8_t* row_valid, void* p_out, void* y_out, case_stream_t stream) {
+  CASE_REQUIRE(d && x && p_out && d->outer > 0 && d->inner > 0 && d->R > 0 && d->C > 0, "case_softmax_fwd: bad argument");
+  CASE_REQUIRE(d->drop_p == 0.f || y_out, "case_softmax_fwd: dropout needs y_out");
+  CASE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "case_softmax_fwd: drop_p out of range");
+  return softmax_dispatch<true>(d, x, col_valid, row_valid, p_out, y_out, (hipStream_t)stream);
+}
+
+extern "C" int case_softmax_bwd(const CaseSoftmaxDesc* d, const void* dy, const void* p, void* dx, case_stream_t stream) {
+  CASE_REQUIRE(d && dy && p && dx && d->outer > 0 && d->inner > 0 && d->R > 0 && d->C > 0, "case_softmax_bwd: bad argument");
+  return softmax_dispatch<false>(d, dy, nullptr, nullptr, (void*)p, dx, (hipStream_t)stream);
+}

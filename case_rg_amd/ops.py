@@ -1,0 +1,834 @@
+"""Differentiable operators of the MI355X path: thin ``torch.autograd.Function`` shells around the C ABI.
+
+PyTorch is used here for device memory (caching allocator), streams and the autograd tape only; every
+arithmetic pass over an activation is a kernel of libcase_hip.so launched through ``_abi`` on the current
+stream.  There is no eager fallback: tensors must live on a ROCm device.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _abi as A
+from . import config
+
+_DT = {torch.float32: A.F32, torch.bfloat16: A.BF16}
+
+
+def _code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("case_rg_amd: unsupported activation dtype %s" % t.dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, offset_elems=0):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("case_rg_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
+    return t.data_ptr() + offset_elems * t.element_size()
+
+
+def _u8(mask):
+    """bool mask -> uint8 view (same storage) or None."""
+    if mask is None:
+        return None
+    m = mask.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter casting: fp32 master -> compute dtype, cached per (storage, version)
+# ----------------------------------------------------------------------------------------------
+_cast_cache = {}
+
+
+def cast_param(p, dtype):
+    """fp32 parameter -> operand of the compute dtype.  bf16 copies are cached until the parameter is
+    updated in place (optimizer step bumps ``_version``)."""
+    src = p.detach()
+    if src.dtype == dtype:
+        return src if src.is_contiguous() else src.contiguous()
+    key = (src.data_ptr(), tuple(src.shape), dtype)
+    hit = _cast_cache.get(key)
+    if hit is not None and hit[0] == p._version:
+        return hit[1]
+    src = src.contiguous()
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    A.call("case_cast", _ptr(src), _ptr(out), src.numel(), _code(src), _DT[dtype], _stream())
+    _cast_cache[key] = (p._version, out)
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    A.call("case_cast", _ptr(x), _ptr(out), x.numel(), _code(x), _DT[dtype], _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# raw GEMM launcher
+# ----------------------------------------------------------------------------------------------
+def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
+         batch1=1, batch2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, epilogue=0, bias_col=None, bias_row=None,
+         aux=None, aux_out=None, ld_aux=0, saux=(0, 0), split_k=1, drop=None):
+    d = A.GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ld_aux = M, N, K, lda, ldb, ldc, ld_aux
+    d.batch1, d.batch2 = batch1, batch2
+    d.sa1, d.sa2 = sa
+    d.sb1, d.sb2 = sb
+    d.sc1, d.sc2 = sc
+    d.saux1, d.saux2 = saux
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.in_dtype, d.out_dtype = _code(a), _code(c)
+    if b.dtype != a.dtype:
+        raise TypeError("gemm operands differ in dtype: %s vs %s" % (a.dtype, b.dtype))
+    if drop is not None and drop[0] > 0.0:
+        epilogue |= A.EPI_DROPOUT
+        d.drop_p, d.seed, d.offset = drop
+    d.epilogue, d.split_k, d.alpha = epilogue, split_k, alpha
+    A.call("case_gemm", d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(bias_row), _ptr(aux),
+           _ptr(aux_out), _stream())
+    return c
+
+
+def _split_for(out_rows, out_cols, k_len, elem_bytes):
+    """split-K factor for weight-gradient GEMMs: enough workgroups to fill 256 CUs twice."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    k_tiles = max(1, (k_len * elem_bytes + 127) // 128)
+    return int(max(1, min(k_tiles, (1024 + tiles - 1) // tiles)))
+
+
+def _weight_grad(g2, x2, N, K):
+    """dW[N, K] = g2[M, N]^T x2[M, K]  (both operands k-major, f32 atomics across K splits)."""
+    M = g2.shape[0]
+    dw = torch.zeros(N, K, dtype=torch.float32, device=g2.device)
+    split = _split_for(N, K, M, g2.element_size())
+    gemm(g2, x2, dw, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC)
+    return dw
+
+
+def _colsum(g2):
+    out = torch.zeros(g2.shape[1], dtype=torch.float32, device=g2.device)
+    A.call("case_colsum", _ptr(g2), _ptr(out), g2.shape[0], g2.shape[1], _code(g2), _stream())
+    return out
+
+
+def _dropout_raw(x, p, seed, offset):
+    y = torch.empty_like(x)
+    A.call("case_dropout", _ptr(x), _ptr(y), x.numel(), p, seed, offset, _code(x), _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# Linear:  y = dropout(x W^T + b) + residual
+# ----------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, residual, p_drop, out_dtype):
+        K, N = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        wc = cast_param(w, x2.dtype)
+        y = torch.empty(M, N, dtype=out_dtype or x2.dtype, device=x2.device)
+        epi, drop, res2 = 0, None, None
+        if b is not None:
+            epi |= A.EPI_BIAS_COL
+        if p_drop > 0.0:
+            seed, off = config.next_rng(M * N)
+            drop = (p_drop, seed, off)
+        if residual is not None:
+            res2 = residual.reshape(M, N).contiguous()
+            epi |= A.EPI_RESIDUAL
+        gemm(x2, wc, y, M, N, K, K, K, N, epilogue=epi, bias_col=b, aux=res2, ld_aux=N, drop=drop)
+        ctx.save_for_backward(x2, wc)
+        ctx.meta = (x.shape, b is not None, residual is not None, drop, w.dtype)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wc = ctx.saved_tensors
+        xshape, has_b, has_res, drop, _ = ctx.meta
+        M, K = x2.shape
+        N = wc.shape[0]
+        d_res = dy if has_res else None
+        g = cast(dy.reshape(M, N), x2.dtype)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if drop is not None:
+            g = _dropout_raw(g, *drop)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+            gemm(g, wc, dx, M, K, N, N, K, K, b_kmajor=True)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            dw = _weight_grad(g, x2, N, K)
+        if has_b and ctx.needs_input_grad[2]:
+            db = _colsum(g)
+        return dx, dw, db, d_res, None, None
+
+
+def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None):
+    return LinearFn.apply(x, w, b, residual, p_drop, out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# Feed-forward pair:  y = dropout_o(W2 dropout_i(act(W1 x + b1)) + b2) + residual
+#   common/TransformerEncoder.py:72-75, TransformerDecoder.py:86-88, TransformerBlock.py:28-29
+# ----------------------------------------------------------------------------------------------
+class FFNFn(Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, p_inner, p_out, residual):
+        K, F_, N = x.shape[-1], w1.shape[0], w2.shape[0]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        w1c, w2c = cast_param(w1, x2.dtype), cast_param(w2, x2.dtype)
+        a = torch.empty(M, F_, dtype=x2.dtype, device=x2.device)
+        z = torch.empty_like(a) if act == "gelu" else None
+        drop_i = drop_o = None
+        if p_inner > 0.0:
+            drop_i = (p_inner,) + config.next_rng(M * F_)
+        if p_out > 0.0:
+            drop_o = (p_out,) + config.next_rng(M * N)
+        gemm(x2, w1c, a, M, F_, K, K, K, F_, epilogue=A.EPI_BIAS_COL | (A.EPI_GELU if act == "gelu" else A.EPI_RELU),
+             bias_col=b1, aux_out=z, ld_aux=F_, drop=drop_i)
+        y = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
+        res2, epi = None, A.EPI_BIAS_COL
+        if residual is not None:
+            res2 = residual.reshape(M, N).contiguous()
+            epi |= A.EPI_RESIDUAL
+        gemm(a, w2c, y, M, N, F_, F_, F_, N, epilogue=epi, bias_col=b2, aux=res2, ld_aux=N, drop=drop_o)
+        ctx.save_for_backward(x2, w1c, w2c, a, z)
+        ctx.meta = (x.shape, act, drop_i, drop_o, residual is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1c, w2c, a, z = ctx.saved_tensors
+        xshape, act, drop_i, drop_o, has_res = ctx.meta
+        M, K = x2.shape
+        F_, N = w1c.shape[0], w2c.shape[0]
+        g = dy.reshape(M, N)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        d_res = dy if has_res else None
+        if drop_o is not None:
+            g = _dropout_raw(g, *drop_o)
+        dw2 = _weight_grad(g, a, N, F_)
+        db2 = _colsum(g)
+        # dz = (g W2) * act'(.) * keep_i/(1-p_i): one GEMM with the derivative (and the regenerated mask) in the epilogue
+        dz = torch.empty(M, F_, dtype=x2.dtype, device=x2.device)
+        if act == "gelu":
+            gemm(g, w2c, dz, M, F_, N, N, F_, F_, b_kmajor=True, epilogue=A.EPI_MUL_DGELU, aux=z, ld_aux=F_, drop=drop_i)
+        else:
+            gemm(g, w2c, dz, M, F_, N, N, F_, F_, b_kmajor=True, epilogue=A.EPI_MUL_DRELU, aux=a, ld_aux=F_, drop=drop_i)
+        dw1 = _weight_grad(dz, x2, F_, K)
+        db1 = _colsum(dz)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+            gemm(dz, w1c, dx, M, K, F_, F_, K, K, b_kmajor=True)
+            dx = dx.view(xshape)
+        return dx, dw1, db1, dw2, db2, None, None, None, d_res
+
+
+def ffn(x, w1, b1, w2, b2, act, p_inner=0.0, p_out=0.0, residual=None):
+    return FFNFn.apply(x, w1, b1, w2, b2, act, p_inner, p_out, residual)
+
+
+# ----------------------------------------------------------------------------------------------
+# LayerNorm (optionally of a sum)
+# ----------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, x2, gamma, beta, eps):
+        C = x.shape[-1]
+        xa = x.reshape(-1, C)
+        xa = xa if xa.is_contiguous() else xa.contiguous()
+        xb = None
+        if x2 is not None:
+            xb = x2.reshape(-1, C)
+            xb = xb if xb.is_contiguous() else xb.contiguous()
+        R = xa.shape[0]
+        y = torch.empty_like(xa)
+        mean = torch.empty(R, dtype=torch.float32, device=xa.device)
+        rstd = torch.empty_like(mean)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        A.call("case_layernorm_fwd", _ptr(xa), _ptr(xb), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), R, C, eps,
+               _code(xa), _stream())
+        ctx.save_for_backward(xa, xb, g, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, g, mean, rstd = ctx.saved_tensors
+        R, C = xa.shape
+        dy2 = dy.reshape(R, C)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = torch.empty_like(xa)
+        dg = torch.zeros(C, dtype=torch.float32, device=xa.device)
+        db = torch.zeros_like(dg)
+        A.call("case_layernorm_bwd", _ptr(dy2), _ptr(xa), _ptr(xb), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg),
+               _ptr(db), R, C, _code(xa), _stream())
+        dx = dx.view(ctx.shape)
+        return dx, (dx if xb is not None else None), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, add=None):
+    return LayerNormFn.apply(x, add, gamma, beta, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# masked softmax over the last dim of a [outer, inner, R, C] view
+# ----------------------------------------------------------------------------------------------
+def _softmax_desc(outer, inner, R, C, causal, in_dt, out_dt, drop):
+    d = A.SoftmaxDesc()
+    d.outer, d.inner, d.R, d.C = outer, inner, R, C
+    d.causal, d.in_dtype, d.out_dtype = int(causal), in_dt, out_dt
+    d.drop_p, d.seed, d.offset = drop if drop is not None else (0.0, 0, 0)
+    return d
+
+
+class SoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, x, col_valid, row_valid, outer, causal, p_drop, out_dtype):
+        """x [..., R, C]; col_valid [outer, C] / row_valid [outer, R] uint8 or None; leading dims = outer*inner."""
+        R, C = x.shape[-2], x.shape[-1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        inner = xc.numel() // (outer * R * C)
+        odt = out_dtype or xc.dtype
+        p = torch.empty(xc.shape, dtype=odt, device=xc.device)
+        drop, y = None, p
+        if p_drop > 0.0:
+            drop = (p_drop,) + config.next_rng(xc.numel())
+            y = torch.empty_like(p)
+        d = _softmax_desc(outer, inner, R, C, causal, _code(xc), _DT[odt], drop)
+        A.call("case_softmax_fwd", d, _ptr(xc), _ptr(col_valid), _ptr(row_valid), _ptr(p), _ptr(y), _stream())
+        ctx.save_for_backward(p)
+        ctx.meta = (outer, inner, R, C, causal, xc.dtype, odt, drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (p,) = ctx.saved_tensors
+        outer, inner, R, C, causal, idt, odt, drop = ctx.meta
+        dyc = cast(dy, odt)
+        dyc = dyc if dyc.is_contiguous() else dyc.contiguous()
+        dx = torch.empty(p.shape, dtype=idt, device=p.device)
+        d = _softmax_desc(outer, inner, R, C, causal, _DT[idt], _DT[odt], drop)
+        A.call("case_softmax_bwd", d, _ptr(dyc), _ptr(p), _ptr(dx), _stream())
+        return dx, None, None, None, None, None, None
+
+
+def masked_softmax(x, col_valid=None, row_valid=None, outer=1, causal=False, p_drop=0.0, out_dtype=None):
+    return SoftmaxFn.apply(x, _u8(col_valid), _u8(row_valid), outer, causal, p_drop, out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# Multi-head attention core on packed projections (K4 / K5 / K6)
+#   S = alpha Q K^T -> masked softmax (+dropout) -> O = P V, heads addressed in place by batch strides.
+# ----------------------------------------------------------------------------------------------
+def _attn_geometry(src, off, heads, d):
+    N, L, W = src.shape
+    return dict(t=src, off=off, ld=W, s1=L * W, s2=d, L=L, N=N)
+
+
+class AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid, causal, p_drop):
+        """*_src: [N, L, W] contiguous tensors holding the projections at column offset *_off (width heads*d);
+        the same tensor may be passed for several roles (packed QKV).  key_valid uint8 [N, Lk] or None."""
+        N, Lq, _ = q_src.shape
+        Lk = k_src.shape[1]
+        dt, dev = q_src.dtype, q_src.device
+        E = heads * d
+        alpha = 1.0 / math.sqrt(d)
+        S = torch.empty(N, heads, Lq, Lk, dtype=dt, device=dev)
+        gemm(q_src, k_src, S, Lq, Lk, d, q_src.shape[2], k_src.shape[2], Lk, a_off=q_off, b_off=k_off, batch1=N, batch2=heads,
+             sa=(Lq * q_src.shape[2], d), sb=(Lk * k_src.shape[2], d), sc=(heads * Lq * Lk, Lq * Lk), alpha=alpha)
+        drop, Pd = None, S
+        if p_drop > 0.0:
+            drop = (p_drop,) + config.next_rng(S.numel())
+            Pd = torch.empty_like(S)
+        sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
+        A.call("case_softmax_fwd", sd, _ptr(S), _ptr(key_valid), None, _ptr(S), _ptr(Pd), _stream())  # in place: S -> P
+        O = torch.empty(N, Lq, E, dtype=dt, device=dev)
+        gemm(Pd, v_src, O, Lq, d, Lk, Lk, v_src.shape[2], E, b_off=v_off, b_kmajor=True, batch1=N, batch2=heads,
+             sa=(heads * Lq * Lk, Lq * Lk), sb=(Lk * v_src.shape[2], d), sc=(Lq * E, d))
+        ctx.save_for_backward(q_src, k_src, v_src, S, Pd if drop is not None else None)
+        ctx.meta = (q_off, k_off, v_off, heads, d, causal, drop, alpha)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q_src, k_src, v_src, P, Pd = ctx.saved_tensors
+        q_off, k_off, v_off, heads, d, causal, drop, alpha = ctx.meta
+        if Pd is None:
+            Pd = P
+        N, Lq, Wq = q_src.shape
+        Lk, Wk, Wv = k_src.shape[1], k_src.shape[2], v_src.shape[2]
+        E = heads * d
+        dt, dev = q_src.dtype, q_src.device
+        dO = dO if dO.is_contiguous() else dO.contiguous()
+        pstr = (heads * Lq * Lk, Lq * Lk)
+        # one gradient buffer per distinct source tensor; slices are written in place by the GEMMs
+        bufs = {}
+
+        def grad_of(src):
+            key = src.data_ptr()
+            if key not in bufs:
+                covered = sum(E for s, _ in ((q_src, 0), (k_src, 0), (v_src, 0)) if s.data_ptr() == key)
+                bufs[key] = (torch.empty_like(src) if covered == src.shape[2] else torch.zeros_like(src))
+            return bufs[key]
+
+        gq, gk, gv = grad_of(q_src), grad_of(k_src), grad_of(v_src)
+        # dP = dO V^T
+        dP = torch.empty(N, heads, Lq, Lk, dtype=dt, device=dev)
+        gemm(dO, v_src, dP, Lq, Lk, d, E, Wv, Lk, b_off=v_off, batch1=N, batch2=heads, sa=(Lq * E, d), sb=(Lk * Wv, d), sc=pstr)
+        # dV = Pd^T dO
+        gemm(Pd, dO, gv, Lk, d, Lq, Lk, E, Wv, c_off=v_off, a_kmajor=True, b_kmajor=True, batch1=N, batch2=heads,
+             sa=pstr, sb=(Lq * E, d), sc=(Lk * Wv, d))
+        # dS = softmax'(dP) in place
+        sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
+        A.call("case_softmax_bwd", sd, _ptr(dP), _ptr(P), _ptr(dP), _stream())
+        # dQ = alpha dS K ; dK = alpha dS^T Q
+        gemm(dP, k_src, gq, Lq, d, Lk, Lk, Wk, Wq, b_off=k_off, c_off=q_off, b_kmajor=True, batch1=N, batch2=heads,
+             sa=pstr, sb=(Lk * Wk, d), sc=(Lq * Wq, d), alpha=alpha)
+        gemm(dP, q_src, gk, Lk, d, Lq, Lk, Wq, Wk, b_off=q_off, c_off=k_off, a_kmajor=True, b_kmajor=True, batch1=N,
+             batch2=heads, sa=pstr, sb=(Lq * Wq, d), sc=(Lk * Wk, d), alpha=alpha)
+        out, seen = [], set()
+        for src in (q_src, k_src, v_src):
+            key = src.data_ptr()
+            out.append(None if key in seen else bufs[key])
+            seen.add(key)
+        return (out[0], out[1], out[2]) + (None,) * 8
+
+
+def attention(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid=None, causal=False, p_drop=0.0):
+    return AttentionFn.apply(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, _u8(key_valid), causal, p_drop)
+
+
+# ----------------------------------------------------------------------------------------------
+# batched matmul for the Interaction chain:  C[n] = A[n] op(B[n])  (+ row / column rank-1 terms)
+# ----------------------------------------------------------------------------------------------
+class BmmFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, b_is_kn, bias_row, bias_col_per_batch, out_dtype):
+        """a [n, M, K]; b [n, N, K] (b_is_kn=False: C = A B^T) or [n, K, N] (True: C = A B).
+        bias_row f32 [n, M] adds to every column; bias_col_per_batch f32 [n, N] is added by a second pass."""
+        n, M, K = a.shape
+        N = b.shape[2] if b_is_kn else b.shape[1]
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        c = torch.empty(n, M, N, dtype=out_dtype or a.dtype, device=a.device)
+        gemm(a, b, c, M, N, K, K, b.shape[2], N, b_kmajor=b_is_kn, batch1=n, sa=(M * K, 0), sb=(b.shape[1] * b.shape[2], 0),
+             sc=(M * N, 0), epilogue=A.EPI_BIAS_ROW if bias_row is not None else 0, bias_row=bias_row)
+        ctx.save_for_backward(a, b)
+        ctx.meta = (b_is_kn, bias_row is not None)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        b_is_kn, has_row = ctx.meta
+        n, M, K = a.shape
+        N = dc.shape[2]
+        g = cast(dc, a.dtype)
+        g = g if g.is_contiguous() else g.contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(b)
+        if b_is_kn:  # C = A B,  B [K, N]:  dA = G B^T (B rows are K, contraction over N -> B is "N_out x Kc" = [K, N]: NT)
+            gemm(g, b, da, M, K, N, N, N, K, batch1=n, sa=(M * N, 0), sb=(K * N, 0), sc=(M * K, 0))
+            # dB[K, N] = A^T G : A k-major [M(Kc), K], G k-major [M(Kc), N]
+            gemm(a, g, db, K, N, M, K, N, N, a_kmajor=True, b_kmajor=True, batch1=n, sa=(M * K, 0), sb=(M * N, 0), sc=(K * N, 0))
+        else:  # C = A B^T, B [N, K]: dA = G B (B k-major: [N(Kc), K]) ; dB[N, K] = G^T A
+            gemm(g, b, da, M, K, N, N, K, K, b_kmajor=True, batch1=n, sa=(M * N, 0), sb=(N * K, 0), sc=(M * K, 0))
+            gemm(g, a, db, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, batch1=n, sa=(M * N, 0), sb=(M * K, 0), sc=(N * K, 0))
+        d_row = dc.float().sum(dim=2) if has_row else None  # [n, M] tiny reduction (glue)
+        return da, db, None, d_row, None, None
+
+
+def bmm(a, b, b_is_kn=False, bias_row=None, out_dtype=None):
+    return BmmFn.apply(a, b, b_is_kn, bias_row, None, out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# K1 embedding + position
+# ----------------------------------------------------------------------------------------------
+class EmbedPosFn(Function):
+    @staticmethod
+    def forward(ctx, ids, table, pe, seq_len, p_drop, dtype):
+        rows, (V, H) = ids.numel(), table.shape
+        ids_c = ids.contiguous()
+        out = torch.empty(*ids.shape, H, dtype=dtype, device=table.device)
+        drop = (p_drop,) + config.next_rng(rows * H) if p_drop > 0.0 else (0.0, 0, 0)
+        scale = math.sqrt(H)
+        A.call("case_embed_pos_fwd", _ptr(ids_c), _ptr(table.detach()), _ptr(pe), _ptr(out), rows, seq_len, H, V, scale, drop[0],
+               drop[1], drop[2], _DT[dtype], _stream())
+        ctx.save_for_backward(ids_c)
+        ctx.meta = (V, H, scale, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (ids_c,) = ctx.saved_tensors
+        V, H, scale, drop = ctx.meta
+        d_out = d_out if d_out.is_contiguous() else d_out.contiguous()
+        d_table = torch.zeros(V, H, dtype=torch.float32, device=d_out.device)
+        A.call("case_embed_pos_bwd", _ptr(ids_c), _ptr(d_out), _ptr(d_table), ids_c.numel(), H, V, scale, drop[0], drop[1],
+               drop[2], _code(d_out), _stream())
+        return None, d_table, None, None, None, None
+
+
+def embed_pos(ids, table, pe, p_drop=0.0, dtype=None):
+    """ids [..., L] -> [..., L, H] = table[ids]*sqrt(H) + pe[position]."""
+    return EmbedPosFn.apply(ids, table, pe, ids.shape[-1], p_drop, dtype or config.compute_dtype())
+
+
+class ScaleAddRowsFn(Function):
+    @staticmethod
+    def forward(ctx, x, pe, scale):
+        L, H = x.shape[-2], x.shape[-1]
+        x = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(x)
+        A.call("case_scale_add_rows", _ptr(x), _ptr(pe), _ptr(y), x.numel() // H, L, H, scale, _code(x), _stream())
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        H = g.shape[-1]
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(g)
+        A.call("case_scale_add_rows", _ptr(g), None, _ptr(dx), g.numel() // H, 1, H, ctx.scale, _code(g), _stream())
+        return dx, None, None
+
+
+def scale_add_rows(x, pe, scale):
+    """x [..., L, H] * scale + pe[:L]  (stand-alone PositionalEmbedding)."""
+    return ScaleAddRowsFn.apply(x, pe, scale)
+
+
+class CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(g, ctx.src), None
+
+
+def cast_to(x, dtype):
+    """Differentiable dtype conversion (identity when already ``dtype``)."""
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# small elementwise ops
+# ----------------------------------------------------------------------------------------------
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        out = torch.empty_like(a)
+        A.call("case_add", _ptr(a), _ptr(b), _ptr(out), a.numel(), _code(a), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.rng = (p,) + config.next_rng(x.numel())
+        return _dropout_raw(x, *ctx.rng)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g if g.is_contiguous() else g.contiguous()
+        return _dropout_raw(g, *ctx.rng), None
+
+
+def dropout(x, p, training=True):
+    p = config.drop_p(p, training)
+    return DropoutFn.apply(x, p) if p > 0.0 else x
+
+
+class MaskRowsFn(Function):
+    @staticmethod
+    def forward(ctx, x, valid_u8):
+        C = x.shape[-1]
+        x = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(x)
+        A.call("case_mask_rows", _ptr(x), _ptr(valid_u8), _ptr(y), x.numel() // C, C, _code(x), _stream())
+        ctx.save_for_backward(valid_u8)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (valid_u8,) = ctx.saved_tensors
+        C = g.shape[-1]
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(g)
+        A.call("case_mask_rows", _ptr(g), _ptr(valid_u8), _ptr(dx), g.numel() // C, C, _code(g), _stream())
+        return dx, None
+
+
+def mask_rows(x, valid):
+    """Zero x[..., r, :] where valid[..., r] is False."""
+    return MaskRowsFn.apply(x, _u8(valid))
+
+
+class ScaleColsFn(Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        C = x.shape[-1]
+        x = x if x.is_contiguous() else x.contiguous()
+        wc = w.detach().contiguous()
+        y = torch.empty_like(x)
+        A.call("case_scale_cols", _ptr(x), _ptr(wc), _ptr(y), x.numel() // C, C, _code(x), _stream())
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wc = ctx.saved_tensors
+        C = x.shape[-1]
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros(C, dtype=torch.float32, device=x.device)
+        A.call("case_scale_cols_bwd", _ptr(g), _ptr(x), _ptr(wc), _ptr(dx), _ptr(dw), x.numel() // C, C, _code(x), _stream())
+        return dx, dw
+
+
+def scale_cols(x, w):
+    return ScaleColsFn.apply(x, w)
+
+
+class MaskedMeanFn(Function):
+    @staticmethod
+    def forward(ctx, x, valid_u8):
+        n, L, H = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty(n, H, dtype=x.dtype, device=x.device)
+        A.call("case_masked_mean_fwd", _ptr(x), _ptr(valid_u8), _ptr(out), n, L, H, _code(x), _stream())
+        ctx.save_for_backward(valid_u8)
+        ctx.shape = (n, L, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (valid_u8,) = ctx.saved_tensors
+        n, L, H = ctx.shape
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty(n, L, H, dtype=g.dtype, device=g.device)
+        A.call("case_masked_mean_bwd", _ptr(g), _ptr(valid_u8), _ptr(dx), n, L, H, _code(g), _stream())
+        return dx, None
+
+
+def masked_mean(x, valid):
+    return MaskedMeanFn.apply(x, _u8(valid))
+
+
+class HighwayGateFn(Function):
+    @staticmethod
+    def forward(ctx, gnl):
+        cols = gnl.shape[-1] // 3
+        gnl = gnl if gnl.is_contiguous() else gnl.contiguous()
+        rows = gnl.numel() // (3 * cols)
+        y = torch.empty(*gnl.shape[:-1], cols, dtype=gnl.dtype, device=gnl.device)
+        A.call("case_highway_gate_fwd", _ptr(gnl), _ptr(y), rows, cols, _code(gnl), _stream())
+        ctx.save_for_backward(gnl)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (gnl,) = ctx.saved_tensors
+        cols = gnl.shape[-1] // 3
+        rows = gnl.numel() // (3 * cols)
+        g = g if g.is_contiguous() else g.contiguous()
+        d = torch.empty_like(gnl)
+        A.call("case_highway_gate_bwd", _ptr(g), _ptr(gnl), _ptr(d), rows, cols, _code(gnl), _stream())
+        return d
+
+
+def highway_gate(gnl):
+    return HighwayGateFn.apply(gnl)
+
+
+class Concat5Fn(Function):
+    @staticmethod
+    def forward(ctx, e, a1, a2, valid_u8):
+        H = e.shape[-1]
+        e, a1, a2 = (t if t.is_contiguous() else t.contiguous() for t in (e, a1, a2))
+        rows = e.numel() // H
+        out = torch.empty(*e.shape[:-1], 5 * H, dtype=e.dtype, device=e.device)
+        A.call("case_concat5_fwd", _ptr(e), _ptr(a1), _ptr(a2), _ptr(valid_u8), _ptr(out), rows, H, _code(e), _stream())
+        ctx.save_for_backward(e, a1, a2, valid_u8)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        e, a1, a2, valid_u8 = ctx.saved_tensors
+        H = e.shape[-1]
+        g = g if g.is_contiguous() else g.contiguous()
+        de, d1, d2 = torch.empty_like(e), torch.empty_like(e), torch.empty_like(e)
+        A.call("case_concat5_bwd", _ptr(g), _ptr(e), _ptr(a1), _ptr(a2), _ptr(valid_u8), _ptr(de), _ptr(d1), _ptr(d2),
+               e.numel() // H, H, _code(e), _stream())
+        return de, d1, d2, None
+
+
+def concat5(e, a1, a2, valid):
+    return Concat5Fn.apply(e, a1, a2, _u8(valid))
+
+
+class MaxOverPFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, P = x.shape[0], x.shape[1]
+        x = x if x.is_contiguous() else x.contiguous()
+        inner = x.numel() // (B * P)
+        out = torch.empty(B, 1, *x.shape[2:], dtype=x.dtype, device=x.device)
+        arg = torch.empty(B * inner, dtype=torch.int32, device=x.device)
+        A.call("case_max_over_p_fwd", _ptr(x), _ptr(out), _ptr(arg), B, P, inner, _code(x), _stream())
+        ctx.save_for_backward(arg)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, P = ctx.shape[0], ctx.shape[1]
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        A.call("case_max_over_p_bwd", _ptr(g), _ptr(arg), _ptr(dx), B, P, dx.numel() // (B * P), _code(g), _stream())
+        return dx
+
+
+def max_over_p(x):
+    return MaxOverPFn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# K7 additive attention scores
+# ----------------------------------------------------------------------------------------------
+class AdditiveScoresFn(Function):
+    @staticmethod
+    def forward(ctx, wq, uh, v):
+        """wq f32 [B, T, H]; uh [B, S, H] (compute dtype); v f32 [H] -> s f32 [B, T, S]."""
+        B, T, H = wq.shape
+        S = uh.shape[1]
+        wq = wq.float().contiguous()
+        uh = uh if uh.is_contiguous() else uh.contiguous()
+        vv = v.detach().float().contiguous()
+        s = torch.empty(B, T, S, dtype=torch.float32, device=wq.device)
+        A.call("case_additive_scores_fwd", _ptr(wq), _ptr(uh), _ptr(vv), _ptr(s), B, T, S, H, _code(uh), _stream())
+        ctx.save_for_backward(wq, uh, vv)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        wq, uh, vv = ctx.saved_tensors
+        B, T, H = wq.shape
+        S = uh.shape[1]
+        ds = ds.float().contiguous()
+        d_wq = torch.empty_like(wq)
+        d_uh = torch.empty(B, S, H, dtype=torch.float32, device=wq.device)
+        d_v = torch.zeros(H, dtype=torch.float32, device=wq.device)
+        A.call("case_additive_scores_bwd", _ptr(ds), _ptr(wq), _ptr(uh), _ptr(vv), _ptr(d_wq), _ptr(d_uh), _ptr(d_v), B, T, S, H,
+               _code(uh), _stream())
+        return d_wq, cast(d_uh, uh.dtype), d_v
+
+
+def additive_scores(wq, uh, v):
+    return AdditiveScoresFn.apply(wq, uh, v)
+
+
+# ----------------------------------------------------------------------------------------------
+# K11 pointer scatter / K12 NLL / K13 argmax
+# ----------------------------------------------------------------------------------------------
+class CopyScatterFn(Function):
+    @staticmethod
+    def forward(ctx, src_ids, w, V, base):
+        """dist[b, t, src[b, s]] += w[b, t, s] on top of ``base`` (or zeros)."""
+        B, T, S = w.shape
+        w = w.float().contiguous()
+        dist = torch.zeros(B, T, V, dtype=torch.float32, device=w.device) if base is None else base.float().clone()
+        A.call("case_copy_scatter_fwd", _ptr(src_ids), _ptr(w), _ptr(dist), B, T, S, V, _stream())
+        ctx.save_for_backward(src_ids)
+        ctx.meta = (B, T, S, V, base is not None)
+        return dist
+
+    @staticmethod
+    def backward(ctx, g):
+        (src_ids,) = ctx.saved_tensors
+        B, T, S, V, has_base = ctx.meta
+        g = g.float().contiguous()
+        d_w = torch.empty(B, T, S, dtype=torch.float32, device=g.device)
+        A.call("case_copy_scatter_bwd", _ptr(src_ids), _ptr(g), _ptr(d_w), B, T, S, V, _stream())
+        return None, d_w, None, (g if has_base else None)
+
+
+def copy_scatter(src_ids, w, V, base=None):
+    return CopyScatterFn.apply(src_ids.contiguous(), w, V, base)
+
+
+class NllGatherFn(Function):
+    @staticmethod
+    def forward(ctx, dist, target):
+        V = dist.shape[-1]
+        dist = dist.float().contiguous()
+        tgt = target.reshape(-1).contiguous()
+        per_row = torch.empty(tgt.numel(), dtype=torch.float32, device=dist.device)
+        A.call("case_nll_gather_fwd", _ptr(dist), _ptr(tgt), _ptr(per_row), tgt.numel(), V, _stream())
+        ctx.save_for_backward(dist, tgt)
+        return per_row
+
+    @staticmethod
+    def backward(ctx, g):
+        dist, tgt = ctx.saved_tensors
+        V = dist.shape[-1]
+        g = g.float().contiguous()
+        d = torch.zeros_like(dist)
+        A.call("case_nll_gather_bwd", _ptr(dist), _ptr(tgt), _ptr(g), _ptr(d), tgt.numel(), V, _stream())
+        return d, None
+
+
+def nll_rows(dist, target):
+    """Per-row -log(dist[target] + 1e-8), 0 where target == 0 (ignore_index)."""
+    return NllGatherFn.apply(dist, target)
+
+
+def row_argmax(x):
+    """[rows, cols] f32 -> (int64 argmax with lowest-index tie break, max value)."""
+    x = x.float()
+    x = x if x.is_contiguous() else x.contiguous()
+    rows, cols = x.shape
+    idx = torch.empty(rows, dtype=torch.int64, device=x.device)
+    val = torch.empty(rows, dtype=torch.float32, device=x.device)
+    A.call("case_row_argmax", _ptr(x), _ptr(idx), _ptr(val), rows, cols, cols, _stream())
+    return idx, val

@@ -1,0 +1,230 @@
+/*
+ * case_hip.h -- C ABI of libcase_hip.so, the MI355X (gfx950) kernel library behind the CaSE_RG
+ * encoder-decoder hot path.
+ *
+ * The reference (PengjieRen/CaSE_RG) has no native layer: every operation below replaces an ATen op
+ * chain called from the reference's Python modules; the chain is cited as <file>:<line> relative to
+ * the reference root.  Host code (case_rg_amd/, Python) binds these entry points with ctypes
+ * (case_rg_amd/_abi.py); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers owned by the caller
+ *     (PyTorch caching allocator).  The library never allocates, frees, retains a pointer or
+ *     synchronises: every call only enqueues work on the caller's stream, so the whole path is
+ *     hipGraph-capturable.
+ *   - return 0 on success, a negative CASE_E_* code otherwise; case_last_error() gives the text.
+ *     Launch errors are read with hipGetLastError() right after enqueue (no sync).
+ *   - dtype arguments are case_dtype_t: activations are f32 (parity mode, exact-f32 MFMA) or bf16
+ *     (throughput mode, bf16 MFMA with f32 accumulate); parameters, statistics, losses and
+ *     gradients of parameters are always f32.
+ *   - masks are uint8 (torch.bool storage), 1 = VALID token unless a name says "pad".
+ */
+#ifndef CASE_HIP_H
+#define CASE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* case_stream_t; /* hipStream_t */
+
+typedef enum { CASE_F32 = 0, CASE_BF16 = 1 } case_dtype_t;
+
+enum {
+  CASE_OK = 0,
+  CASE_E_ARG = -1,         /* bad shape / stride / null pointer */
+  CASE_E_UNSUPPORTED = -2, /* combination not built */
+  CASE_E_LAUNCH = -3       /* hipGetLastError() after enqueue */
+};
+
+int case_version(void);
+const char* case_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  strided-batched GEMM on MFMA:   C = epilogue(alpha * op(A) op(B))
+ * replaces every nn.Linear / MHA in_proj / out_proj / bmm on the path:
+ *   common/TransformerEncoder.py:67,72  common/TransformerDecoder.py:77,81,86
+ *   common/TransformerBlock.py:26,28-29  common/Interaction.py:36,50-54  common/BilinearAttention.py:31,34,57
+ *   CaSE/Model.py:34,36,43,242  (and their autograd backward)
+ * A is M x K, B is N x K ("NT": C = A B^T) unless *_kmajor says the operand is stored K x M / K x N.
+ * Batch index b in [0, batch1*batch2): b1 = b / batch2, b2 = b % batch2 (b2 = attention head);
+ * operand offset = b1*s?1 + b2*s?2 elements.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+  CASE_EPI_BIAS_COL = 1,   /* + bias_col[n] (f32)                                   */
+  CASE_EPI_BIAS_ROW = 2,   /* + bias_row[b*M + m] (f32)  (Interaction rank-1 terms) */
+  CASE_EPI_GELU = 4,       /* erf GELU; pre-activation also stored to aux_out if non-null */
+  CASE_EPI_RELU = 8,
+  CASE_EPI_RESIDUAL = 16,  /* + aux[m, n]                                           */
+  CASE_EPI_MUL_DGELU = 32, /* * gelu'(aux[m, n])   (backward through GELU)          */
+  CASE_EPI_MUL_DRELU = 64, /* * (aux[m, n] > 0)    (backward through ReLU; aux = activation output) */
+  CASE_EPI_ATOMIC = 128,   /* split-K: atomicAdd f32 into pre-zeroed C (out_dtype must be f32) */
+  CASE_EPI_DROPOUT = 256   /* * keep(seed, offset + (b*M + m)*N + n) / (1 - drop_p); nn.Dropout / F.dropout sites:
+                              TransformerEncoder.py:68,72,75 TransformerDecoder.py:78,82,86,88 TransformerBlock.py:27-28
+                              CaSE/Model.py:34.  The same flag regenerates the mask in the backward GEMM. */
+};
+/* epilogue order: alpha*acc + bias -> GELU|RELU -> MUL_DGELU|MUL_DRELU -> DROPOUT -> + RESIDUAL */
+
+typedef struct {
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc, ld_aux; /* leading dimensions in elements */
+  int64_t batch1, batch2;
+  int64_t sa1, sa2, sb1, sb2, sc1, sc2, saux1, saux2;
+  int32_t a_kmajor, b_kmajor;
+  int32_t in_dtype;  /* dtype of A, B, aux, aux_out */
+  int32_t out_dtype; /* dtype of C */
+  int32_t epilogue;  /* CASE_EPI_* mask */
+  int32_t split_k;   /* >= 1 */
+  float alpha;
+  float drop_p;
+  uint64_t seed, offset;
+} CaseGemmDesc;
+
+int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
+              const float* bias_row, const void* aux, void* aux_out, case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  embedding gather * sqrt(H) + sinusoid position (+ dropout)
+ *   common/TransformerSeqEncoderDecoder.py:21,36  common/PositionalEmbedding.py:44-48  CaSE/Model.py:21,67
+ * ids int64 [rows]; position of a row = row % seq_len; table f32 [V, H]; pe f32 [>= seq_len, H].
+ * bwd: d_table[id] += scale * d_out[row] (f32 atomics; id 0 = padding_idx receives nothing).
+ * ------------------------------------------------------------------------------------------- */
+int case_embed_pos_fwd(const int64_t* ids, const float* table, const float* pe, void* out, int64_t rows,
+                       int64_t seq_len, int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed,
+                       uint64_t offset, int32_t dtype, case_stream_t stream);
+int case_embed_pos_bwd(const int64_t* ids, const void* d_out, float* d_table, int64_t rows, int64_t H,
+                       int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
+                       case_stream_t stream);
+
+/* stand-alone PositionalEmbedding.forward (common/PositionalEmbedding.py:44-48): y = x*scale + pe[row % seq_len]
+ * (pe may be null: plain scaling, used as its backward) */
+int case_scale_add_rows(const void* x, const float* pe, void* y, int64_t rows, int64_t seq_len, int64_t H, float scale,
+                        int32_t dtype, case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  LayerNorm (eps inside sqrt, affine), optional fused input add: y = LN(x + x2)
+ *   common/TransformerEncoder.py:66,70  common/TransformerDecoder.py:76,80,84  common/TransformerBlock.py:25,28
+ *   CaSE/Model.py:69,84,209-210
+ * mean / rstd f32 [rows] are saved for backward.  bwd accumulates d_gamma / d_beta with f32 atomics
+ * into pre-zeroed buffers; dx is also the gradient of x2 when the add was fused.
+ * ------------------------------------------------------------------------------------------- */
+int case_layernorm_fwd(const void* x, const void* x2, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, case_stream_t stream);
+int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, float* d_gamma, float* d_beta, int64_t rows, int64_t cols,
+                       int32_t dtype, case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4/K5/K6 (softmax stage) and the masked softmaxes of K7/K8/K10/K11
+ *   torch MHA softmax (common/TransformerEncoder.py:67, TransformerDecoder.py:77,81, TransformerBlock.py:26),
+ *   common/Interaction.py:43-47, common/BilinearAttention.py:16-19, CaSE/Model.py:34,39
+ * x is [outer, inner, R, C] contiguous; softmax over C.  col_valid u8 [outer, C] (or null), row_valid u8
+ * [outer, R] (or null), causal: column > row masked.  A row with no admissible column yields exact 0
+ * (the reference's NaN -> masked_fill(0) path) and zero gradient.
+ * p_out: probabilities (saved for backward); y_out: after dropout (may alias p_out when drop_p == 0).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t outer, inner, R, C;
+  int32_t causal;
+  int32_t in_dtype, out_dtype;
+  float drop_p;
+  uint64_t seed, offset;
+} CaseSoftmaxDesc;
+
+int case_softmax_fwd(const CaseSoftmaxDesc* d, const void* x, const uint8_t* col_valid, const uint8_t* row_valid,
+                     void* p_out, void* y_out, case_stream_t stream);
+int case_softmax_bwd(const CaseSoftmaxDesc* d, const void* dy, const void* p, void* dx, case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * elementwise / small reductions
+ * ------------------------------------------------------------------------------------------- */
+/* out = a + b  (residual adds: TransformerEncoder.py:68,75 etc.) */
+int case_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, case_stream_t stream);
+/* dropout with a counter RNG keyed by (seed, offset + element index); same call regenerates the mask in bwd */
+int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,
+                 case_stream_t stream);
+/* zero rows whose valid flag is 0: TransformerBlock.py:31, Interaction.py:68-70 */
+int case_mask_rows(const void* x, const uint8_t* row_valid, void* y, int64_t rows, int64_t cols, int32_t dtype,
+                   case_stream_t stream);
+/* column sums of a [rows, cols] matrix into f32 [cols] (bias gradients); out must be pre-zeroed */
+int case_colsum(const void* x, float* out, int64_t rows, int64_t cols, int32_t dtype, case_stream_t stream);
+/* dtype conversion (f32 master weights -> bf16 operands) */
+int case_cast(const void* x, void* y, int64_t n, int32_t src_dtype, int32_t dst_dtype, case_stream_t stream);
+/* y[r, :] = x[r, :] * w[:]  (Interaction: Ep * w3); bwd dx = dy * w, dw += colsum(dy * x) */
+int case_scale_cols(const void* x, const float* w, void* y, int64_t rows, int64_t cols, int32_t dtype,
+                    case_stream_t stream);
+int case_scale_cols_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int64_t rows,
+                        int64_t cols, int32_t dtype, case_stream_t stream);
+/* masked mean over the sequence: common/Utils.py:455-470.  x [n, L, H], valid u8 [n, L] -> out [n, H] */
+int case_masked_mean_fwd(const void* x, const uint8_t* valid, void* out, int64_t n, int64_t L, int64_t H,
+                         int32_t dtype, case_stream_t stream);
+int case_masked_mean_bwd(const void* d_out, const uint8_t* valid, void* dx, int64_t n, int64_t L, int64_t H,
+                         int32_t dtype, case_stream_t stream);
+/* Highway gate: y = sigmoid(g) * tanh(nl) + (1 - sigmoid(g)) * lin  (common/Highway.py:29-35).
+ * gnl is [rows, 3*cols] = [g | nl | lin] (one fused GEMM output). */
+int case_highway_gate_fwd(const void* gnl, void* y, int64_t rows, int64_t cols, int32_t dtype, case_stream_t stream);
+int case_highway_gate_bwd(const void* dy, const void* gnl, void* d_gnl, int64_t rows, int64_t cols, int32_t dtype,
+                          case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  Interaction feature assembly: common/Interaction.py:65-74
+ *   out[r, :] = valid[r] ? [e, a1, a2, e*a1, e*a2] : 0     (each [rows, H] -> [rows, 5H])
+ *   bwd returns de, da1, da2.
+ *   max over passages for the query side (num_q == 1): x [B, P, L, W] -> out [B, L, W], argmax int32
+ * ------------------------------------------------------------------------------------------- */
+int case_concat5_fwd(const void* e, const void* a1, const void* a2, const uint8_t* row_valid, void* out,
+                     int64_t rows, int64_t H, int32_t dtype, case_stream_t stream);
+int case_concat5_bwd(const void* d_out, const void* e, const void* a1, const void* a2, const uint8_t* row_valid,
+                     void* de, void* da1, void* da2, int64_t rows, int64_t H, int32_t dtype, case_stream_t stream);
+int case_max_over_p_fwd(const void* x, void* out, int32_t* argmax, int64_t B, int64_t P, int64_t inner, int32_t dtype,
+                        case_stream_t stream);
+int case_max_over_p_bwd(const void* d_out, const int32_t* argmax, void* dx, int64_t B, int64_t P, int64_t inner,
+                        int32_t dtype, case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  additive (Bahdanau) attention scores: common/BilinearAttention.py:24-46
+ *   s[b, t, j] = sum_h v[h] * tanh(wq[b, t, h] + uh[b, j, h])      (never materialises [B, T, S, H])
+ * wq f32 [B, T, H] (small: the query projection is produced in f32), uh [B, S, H] in dtype; v f32 [H];
+ * s f32 [B, T, S].
+ * bwd: given ds f32 [B, T, S]:  d_wq[b,t,h] = sum_j g, d_uh[b,j,h] = sum_t g, d_v[h] = sum ds*tanh,
+ *      g = ds * v[h] * (1 - tanh^2);  d_wq, d_uh are f32 and fully written; d_v is f32 and must be
+ *      pre-zeroed (one coalesced atomic per h per workgroup).
+ * ------------------------------------------------------------------------------------------- */
+int case_additive_scores_fwd(const float* wq, const void* uh, const float* v, float* s, int64_t B, int64_t T,
+                             int64_t S, int64_t H, int32_t dtype, case_stream_t stream);
+int case_additive_scores_bwd(const float* ds, const float* wq, const void* uh, const float* v, float* d_wq,
+                             float* d_uh, float* d_v, int64_t B, int64_t T, int64_t S, int64_t H, int32_t dtype,
+                             case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K11 copy / pointer distribution: CaSE/Model.py:38-48 with common/Utils.py:344-355
+ *   dist[b, t, src[b, s]] += w[b, t, s]        (scatter-add instead of the dense one-hot bmm)
+ * src int64 [B, S]; w f32 [B, T, S]; dist f32 [B, T, V] (caller zero-fills or pre-loads dist1).
+ * bwd: d_w[b, t, s] = d_dist[b, t, src[b, s]].
+ * ------------------------------------------------------------------------------------------- */
+int case_copy_scatter_fwd(const int64_t* src, const float* w, float* dist, int64_t B, int64_t T, int64_t S,
+                          int64_t V, case_stream_t stream);
+int case_copy_scatter_bwd(const int64_t* src, const float* d_dist, float* d_w, int64_t B, int64_t T, int64_t S,
+                          int64_t V, case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K12 losses
+ *   NLL of log(dist + 1e-8) at the target, ignore_index = 0 (CaSE/Model.py:306, Masque/Model.py:239):
+ *     per_row[r] = target[r] ? -log(dist[r, target[r]] + 1e-8) : 0 ; bwd writes only the target column
+ *     into a pre-zeroed d_dist: d_dist[r, y] = -g_row[r] / (dist[r, y] + 1e-8)
+ *   Row argmax with lowest-index tie break (common/Utils.py:167) for greedy decoding (K13).
+ * ------------------------------------------------------------------------------------------- */
+int case_nll_gather_fwd(const float* dist, const int64_t* target, float* per_row, int64_t rows, int64_t V,
+                        case_stream_t stream);
+int case_nll_gather_bwd(const float* dist, const int64_t* target, const float* g_row, float* d_dist, int64_t rows,
+                        int64_t V, case_stream_t stream);
+int case_row_argmax(const float* x, int64_t* idx, float* val, int64_t rows, int64_t cols, int64_t ld,
+                    case_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASE_HIP_H */

@@ -1,0 +1,255 @@
+"""Kernel-level numerics on the MI355X: every C-ABI op (through its autograd shell in case_rg_amd.ops)
+against a plain PyTorch fp32 reference of the same op, forward and gradients.
+
+Tolerances: f32 mode 1e-3 relative to the tensor scale (north-star bar; the exact-f32 MFMA path is usually
+~1e-6); bf16 mode is reported against its own bar (3e-2 of the tensor scale, bf16 has 8 mantissa bits)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from case_rg_amd import config, ops
+    config.set_dropout(False)
+    return ops
+
+
+def _close(got, want, tol, what):
+    got, want = got.float(), want.float()
+    scale = want.abs().max().item() + 1e-6
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (tol %.1e)" % (what, err, scale, tol)
+
+
+def _tol(dt):
+    return 1e-3 if dt == torch.float32 else 3e-2
+
+
+def _rand(*shape, dt=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(256, 512, 384), (300, 136, 200), (7, 20, 5), (129, 64, 1), (1024, 2560, 512)])
+def test_linear_fwd_bwd(dt, M, K, N):
+    ops = _ops()
+    x = _rand(M, K, dt=dt, seed=1).requires_grad_()
+    w = _rand(N, K, seed=2, scale=K ** -0.5).requires_grad_()
+    b = _rand(N, seed=3).requires_grad_()
+    res = _rand(M, N, dt=dt, seed=4).requires_grad_()
+    y = ops.linear(x, w, b, residual=res)
+    xr, wr, br, rr = [t.detach().float().requires_grad_() for t in (x, w.to(dt), b, res)]
+    yr = F.linear(xr, wr, br) + rr
+    _close(y, yr, _tol(dt), "linear y")
+    g = _rand(M, N, dt=dt, seed=5)
+    y.backward(g)
+    yr.backward(g.float())
+    _close(x.grad, xr.grad, _tol(dt), "linear dx")
+    _close(w.grad, wr.grad, _tol(dt), "linear dw")
+    _close(b.grad, br.grad, _tol(dt), "linear db")
+    _close(res.grad, rr.grad, _tol(dt), "linear dres")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_ffn(dt, act):
+    ops = _ops()
+    M, K, Fh, N = 200, 96, 72, 96
+    x = _rand(M, K, dt=dt, seed=1).requires_grad_()
+    w1, b1 = _rand(Fh, K, seed=2, scale=K ** -0.5).requires_grad_(), _rand(Fh, seed=3).requires_grad_()
+    w2, b2 = _rand(N, Fh, seed=4, scale=Fh ** -0.5).requires_grad_(), _rand(N, seed=5).requires_grad_()
+    y = ops.ffn(x, w1, b1, w2, b2, act, residual=x)
+    ps = [x, w1, b1, w2, b2]
+    rs = [t.detach().to(dt).float().requires_grad_() if t.dim() == 2 and t is not x else t.detach().float().requires_grad_() for t in ps]
+    fa = F.gelu if act == "gelu" else F.relu
+    yr = F.linear(fa(F.linear(rs[0], rs[1], rs[2])), rs[3], rs[4]) + rs[0]
+    _close(y, yr, _tol(dt), "ffn y")
+    g = _rand(M, N, dt=dt, seed=6)
+    y.backward(g)
+    yr.backward(g.float())
+    for name, a, r in zip(["dx", "dw1", "db1", "dw2", "db2"], ps, rs):
+        _close(a.grad, r.grad, 2 * _tol(dt), "ffn " + name)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(33, 32), (100, 2560), (5, 160)])
+def test_layernorm(dt, R, C):
+    ops = _ops()
+    x = _rand(R, C, dt=dt, seed=1).requires_grad_()
+    x2 = _rand(R, C, dt=dt, seed=2).requires_grad_()
+    g, b = (1 + 0.1 * _rand(C, seed=3)).requires_grad_(), _rand(C, seed=4).requires_grad_()
+    y = ops.layer_norm(x, g, b, add=x2)
+    xr, x2r, gr, br = [t.detach().float().requires_grad_() for t in (x, x2, g, b)]
+    yr = F.layer_norm(xr + x2r, (C,), gr, br)
+    _close(y, yr, _tol(dt), "ln y")
+    go = _rand(R, C, dt=dt, seed=5)
+    y.backward(go)
+    yr.backward(go.float())
+    _close(x.grad, xr.grad, _tol(dt), "ln dx")
+    _close(x2.grad, x2r.grad, _tol(dt), "ln dx2")
+    _close(g.grad, gr.grad, _tol(dt), "ln dgamma")
+    _close(b.grad, br.grad, _tol(dt), "ln dbeta")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,h,Lq,Lk,d,causal", [(3, 8, 7, 7, 4, False), (2, 8, 5, 5, 4, True), (2, 8, 40, 72, 64, False),
+                                                 (2, 8, 96, 96, 320, False), (2, 4, 13, 200, 20, False)])
+def test_attention(dt, N, h, Lq, Lk, d, causal):
+    ops = _ops()
+    E = h * d
+    self_attn = Lq == Lk
+    valid = torch.ones(N, Lk, dtype=torch.bool, device=DEV)
+    valid[1, Lk // 2 + 1:] = False
+    if self_attn:
+        qkv = _rand(N, Lq, 3 * E, dt=dt, seed=1, scale=0.5).requires_grad_()
+        o = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=valid, causal=causal)
+        r = qkv.detach().float().requires_grad_()
+        q, k, v = r.split(E, dim=-1)
+    else:
+        qs = _rand(N, Lq, E, dt=dt, seed=1, scale=0.5).requires_grad_()
+        kv = _rand(N, Lk, 2 * E, dt=dt, seed=2, scale=0.5).requires_grad_()
+        o = ops.attention(qs, kv, kv, 0, 0, E, h, d, key_valid=valid, causal=causal)
+        rq, rkv = qs.detach().float().requires_grad_(), kv.detach().float().requires_grad_()
+        q, (k, v) = rq, rkv.split(E, dim=-1)
+    qh, kh, vh = [t.reshape(N, -1, h, d).transpose(1, 2) for t in (q, k, v)]
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(d)
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    if causal:
+        s = s + torch.triu(torch.full((Lq, Lk), -1e20, device=DEV), 1)
+    orf = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(N, Lq, E)
+    _close(o, orf, _tol(dt), "attn o")
+    g = _rand(N, Lq, E, dt=dt, seed=3)
+    o.backward(g)
+    orf.backward(g.float())
+    if self_attn:
+        _close(qkv.grad, r.grad, 2 * _tol(dt), "attn dqkv")
+    else:
+        _close(qs.grad, rq.grad, 2 * _tol(dt), "attn dq")
+        _close(kv.grad, rkv.grad, 2 * _tol(dt), "attn dkv")
+
+
+def test_softmax_masks_and_empty_rows():
+    ops = _ops()
+    x = _rand(2, 6, 9, seed=1).requires_grad_()
+    cv = torch.ones(2, 9, dtype=torch.bool, device=DEV)
+    cv[0, 5:] = False
+    rv = torch.ones(2, 6, dtype=torch.bool, device=DEV)
+    rv[1, 4:] = False
+    p = ops.masked_softmax(x, cv, rv, outer=2)
+    xr = x.detach().clone().requires_grad_()
+    m = rv[:, :, None] & cv[:, None, :]
+    pr = torch.softmax(xr.masked_fill(~m, float("-inf")), -1).masked_fill(~m, 0.0)
+    _close(p, pr, 1e-5, "softmax p")
+    assert (p[1, 4:] == 0).all(), "fully masked rows must be exactly zero"
+    g = _rand(2, 6, 9, seed=2)
+    p.backward(g)
+    pr.backward(g)
+    _close(x.grad, torch.nan_to_num(xr.grad), 1e-5, "softmax dx")
+    assert (x.grad[1, 4:] == 0).all()
+    # wide rows take the workgroup-per-row kernel
+    xw = _rand(3, 3000, seed=3)
+    _close(ops.masked_softmax(xw.view(1, 3, 3000)), torch.softmax(xw, -1).view(1, 3, 3000), 1e-5, "softmax wide")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_additive_scores(dt):
+    ops = _ops()
+    B, T, S, H = 2, 11, 150, 96
+    wq = _rand(B, T, H, seed=1).requires_grad_()
+    uh = _rand(B, S, H, dt=dt, seed=2).requires_grad_()
+    v = _rand(H, seed=3).requires_grad_()
+    s = ops.additive_scores(wq, uh, v)
+    wr, ur, vr = [t.detach().float().requires_grad_() for t in (wq, uh, v)]
+    sr = torch.tanh(wr[:, :, None, :] + ur[:, None, :, :]) @ vr
+    tol = 1e-3 if dt == torch.float32 else 1e-2
+    _close(s, sr, tol, "additive s")
+    g = _rand(B, T, S, seed=4)
+    s.backward(g)
+    sr.backward(g)
+    _close(wq.grad, wr.grad, tol, "additive dwq")
+    _close(uh.grad, ur.grad, 3 * tol, "additive duh")
+    _close(v.grad, vr.grad, tol, "additive dv")
+
+
+def test_embed_pos_and_pointer_and_nll():
+    ops = _ops()
+    from oracle import sinusoid_table
+    V, H, L = 50, 24, 9
+    ids = torch.randint(0, V, (3, 2, L), generator=torch.Generator().manual_seed(1)).to(DEV)
+    table = _rand(V, H, seed=2).requires_grad_()
+    pe = sinusoid_table(20, H).to(DEV)
+    y = ops.embed_pos(ids, table, pe, dtype=torch.float32)
+    tr = table.detach().clone().requires_grad_()
+    yr = F.embedding(ids, tr, padding_idx=0) * math.sqrt(H) + pe[:L]
+    _close(y, yr, 1e-6, "embed y")
+    g = _rand(3, 2, L, H, seed=3)
+    y.backward(g)
+    yr.backward(g)
+    _close(table.grad, tr.grad, 1e-5, "embed dtable")
+    # pointer scatter == dense one-hot bmm (common/Utils.py:344-355 + CaSE/Model.py:43)
+    B, T, S = 2, 5, 17
+    src = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(4)).to(DEV)
+    w = _rand(B, T, S, seed=5).abs().requires_grad_()
+    d = ops.copy_scatter(src, w, V)
+    wr = w.detach().clone().requires_grad_()
+    dr = wr @ F.one_hot(src, V).float()
+    _close(d, dr, 1e-5, "scatter dist")
+    gd = _rand(B, T, V, seed=6)
+    d.backward(gd)
+    dr.backward(gd)
+    _close(w.grad, wr.grad, 1e-6, "scatter dw")
+    # nll with ignore_index 0
+    dist = torch.softmax(_rand(B * T, V, seed=7), -1).requires_grad_()
+    tgt = torch.randint(0, V, (B * T,), generator=torch.Generator().manual_seed(8)).to(DEV)
+    tgt[0] = 0
+    rows = ops.nll_rows(dist, tgt)
+    dr2 = dist.detach().clone().requires_grad_()
+    ref = F.nll_loss((dr2 + 1e-8).log(), tgt, ignore_index=0, reduction="none")
+    _close(rows, ref, 1e-5, "nll rows")
+    rows.sum().backward()
+    ref.sum().backward()
+    _close(dist.grad, dr2.grad, 1e-5, "nll ddist")
+    # argmax ties -> lowest index
+    x = torch.tensor([[0.1, 0.7, 0.7, 0.05], [0.3, 0.3, 0.2, 0.3]], device=DEV)
+    idx, val = ops.row_argmax(x)
+    assert idx.tolist() == [1, 0] and val.tolist() == pytest.approx([0.7, 0.3])
+
+
+def test_dropout_mask_is_regenerated_in_backward():
+    from case_rg_amd import config, ops
+    config.set_dropout(True)
+    config.manual_seed(7)
+    try:
+        x = torch.ones(1000, 64, device=DEV, requires_grad=True)
+        y = ops.dropout(x, 0.1, training=True)
+        keep = (y != 0)
+        assert 0.85 < keep.float().mean().item() < 0.95
+        _close(y[keep], torch.full_like(y[keep], 1 / 0.9), 1e-6, "dropout scale")
+        y.sum().backward()
+        assert torch.equal(x.grad != 0, keep), "backward must regenerate the same mask"
+        # GEMM-epilogue dropout: same statistics, backward consistent with forward mask
+        w = torch.eye(64, device=DEV).requires_grad_()
+        x2 = torch.ones(512, 64, device=DEV, requires_grad=True)
+        z = ops.linear(x2, w, None, p_drop=0.25)
+        kz = z != 0
+        assert 0.70 < kz.float().mean().item() < 0.80
+        z.sum().backward()
+        assert torch.equal(x2.grad != 0, kz)
+    finally:
+        config.set_dropout(False)
+
+
+def test_gemm_rejects_bad_arguments():
+    from case_rg_amd import ops
+    a = torch.zeros(4, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="case_gemm"):
+        ops.gemm(a, a, a, 0, 4, 4, 4, 4, 4)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear(torch.zeros(2, 2), torch.zeros(2, 2))
