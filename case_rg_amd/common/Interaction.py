@@ -1,0 +1,57 @@
+"""Query/passage dual co-attention (reference: common/Interaction.py:5-75).
+
+With w = [w1; w2; w3] = dual_att_linear.weight:
+    U[n,i,j] = w1.Eq[j] + w2.Ep[i] + (w3 * Ep[i]).Eq[j]
+which equals the reference's Linear(cat[Eq, Ep, Eq*Ep]) (:32-36) without the [n, Lp, Lq, 3H] tensor (48 GB at
+cfg 2).  U and its transpose come from two small MFMA GEMMs (rank-1 terms in the epilogue), the row softmaxes
+of both give A = softmax_j and Bm^T = softmax_i directly in the layouts the four follow-up bmm need:
+    A1 = A Eq, B1 = Bm^T Ep, A2 = A B1, B2 = Bm^T A1
+    G_q_p = [Ep, A1, A2, Ep*A1, Ep*A2] (0 at pads), G_p_q = [Eq, B1, B2, Eq*B1, Eq*B2] (0 at pads; max over
+    passages when one query faces P passages, :73-74).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class Interaction(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.dual_att_linear = nn.Linear(3 * hidden_size, 1, bias=False)
+
+    def forward(self, encode_input1, encode_input2, input1_mask, input2_mask):
+        B, nq, Lq, H = encode_input1.shape
+        _, P, Lp, _ = encode_input2.shape
+        if nq != P:
+            assert nq == 1
+            Eq = encode_input1.expand(-1, P, -1, -1)
+            qv = input1_mask.expand(-1, P, -1)
+        else:
+            Eq, qv = encode_input1, input1_mask
+        n = B * P
+        Eq = Eq.reshape(n, Lq, H)
+        Ep = encode_input2.reshape(n, Lp, H)
+        qv = qv.reshape(n, Lq).contiguous()
+        pv = input2_mask.reshape(n, Lp).contiguous()
+        w = self.dual_att_linear.weight
+        w1, w2, w3 = w[:, :H], w[:, H:2 * H], w[0, 2 * H:]
+        f32 = torch.float32
+        cq = ops.linear(Eq, w1, out_dtype=f32).reshape(n, Lq)  # w1 . Eq[j]
+        ap = ops.linear(Ep, w2, out_dtype=f32).reshape(n, Lp)  # w2 . Ep[i]
+        Epw = ops.scale_cols(Ep, w3)
+        U = ops.bmm(Epw, Eq, bias_row=ap, out_dtype=f32) + cq.unsqueeze(1)   # [n, Lp, Lq]
+        Ut = ops.bmm(Eq, Epw, bias_row=cq, out_dtype=f32) + ap.unsqueeze(1)  # [n, Lq, Lp]
+        dt = Ep.dtype
+        A = ops.masked_softmax(U, qv, pv, outer=n, out_dtype=dt)    # softmax over the query axis
+        Bt = ops.masked_softmax(Ut, pv, qv, outer=n, out_dtype=dt)  # softmax over the passage axis, transposed
+        A1 = ops.bmm(A, Eq, b_is_kn=True)    # [n, Lp, H]
+        B1 = ops.bmm(Bt, Ep, b_is_kn=True)   # [n, Lq, H]
+        A2 = ops.bmm(A, B1, b_is_kn=True)
+        B2 = ops.bmm(Bt, A1, b_is_kn=True)
+        G_q_p = ops.concat5(Ep, A1, A2, pv).reshape(B, P, Lp, 5 * H)
+        G_p_q = ops.concat5(Eq, B1, B2, qv).reshape(B, P, Lq, 5 * H)
+        if nq != P:
+            G_p_q = ops.max_over_p(G_p_q)
+        return G_p_q, G_q_p

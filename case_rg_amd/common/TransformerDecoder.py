@@ -1,0 +1,116 @@
+"""Decoder layers / stack on the HIP path (reference: common/TransformerDecoder.py:21-90, :95-164, :169-218).
+
+    x = LN1(x); x += drop(SelfAttn(x; causal, key pad)); x = LN2(x); x += drop(CrossAttn(x, memory; key pad));
+    x = LN3(x); x += drop(W2 drop(act(W1 x)))
+The layers return ``(x, None, None)``: the head-averaged attention weights of the reference are discarded
+by every caller on the path and are not materialised here.
+"""
+import torch
+import torch.nn as nn
+
+from .. import config, ops
+from .attention import MultiheadAttention, is_causal_mask
+from .Highway import Highway
+from .TransformerEncoder import _check_activation, _get_clones
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.p = dropout
+        self.activation = _check_activation(activation)
+
+    def forward_batch_first(self, x, memory, tgt_valid=None, memory_valid=None, causal=True, memory_kv=None):
+        """x [N, T, E]; memory [N, S, E]; *_valid bool True = token."""
+        p = config.drop_p(self.p, self.training)
+        x = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.self_attn.self_attention(x, tgt_valid, causal=causal, residual=x, p_res=self.p)
+        x = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = self.multihead_attn.cross_attention(x, memory, memory_valid, residual=x, p_res=self.p, kv=memory_kv)
+        x = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                       self.activation, p_inner=p, p_out=p, residual=x)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        if memory_mask is not None:
+            raise NotImplementedError("memory_mask is not used on the CaSE path")
+        tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
+        mv = None if memory_key_padding_mask is None else ~memory_key_padding_mask
+        y = self.forward_batch_first(tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), tv, mv,
+                                     causal=is_causal_mask(tgt_mask))
+        return y.transpose(0, 1), None, None
+
+
+class GenericTransformerDecoderLayer(nn.Module):
+    """Multi-memory variant that merges each attention through Highway(2E -> E) instead of a residual
+    (reference :95-164; not instantiated by CaSE / Masque, kept for API completeness)."""
+
+    def __init__(self, nmemory, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.self_norm = nn.LayerNorm(d_model)
+        self.self_highway = Highway(2 * d_model, d_model)
+        self.memory_attns = nn.ModuleList([MultiheadAttention(d_model, nhead, dropout=dropout) for _ in range(nmemory)])
+        self.memory_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(nmemory)])
+        self.memory_highways = nn.ModuleList([Highway(2 * d_model, d_model) for _ in range(nmemory)])
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.p = dropout
+        self.activation = _check_activation(activation)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        p = config.drop_p(self.p, self.training)
+        tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
+        x = tgt.transpose(0, 1).contiguous()
+        x = ops.layer_norm(x, self.self_norm.weight, self.self_norm.bias, self.self_norm.eps)
+        a = self.self_attn.self_attention(x, tv, causal=is_causal_mask(tgt_mask), p_res=self.p)
+        x = self.self_highway(torch.cat([x, a], dim=-1))
+        for i, mem in enumerate(memory):
+            norm = self.memory_norms[i]
+            x = ops.layer_norm(x, norm.weight, norm.bias, norm.eps)
+            kp = None if memory_key_padding_mask is None else memory_key_padding_mask[i]
+            c = self.memory_attns[i].cross_attention(x, mem.transpose(0, 1).contiguous(), None if kp is None else ~kp,
+                                                     p_res=self.p)
+            x = self.memory_highways[i](torch.cat([x, c], dim=-1))
+        y = ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
+                    p_inner=p, p_out=p, residual=x)
+        return y.transpose(0, 1), None, None
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward_batch_first(self, x, memory, tgt_valid=None, memory_valid=None, causal=True, memory_kvs=None):
+        for i, layer in enumerate(self.layers):
+            x = layer.forward_batch_first(x, memory, tgt_valid, memory_valid, causal,
+                                          None if memory_kvs is None else memory_kvs[i])
+        if self.norm is not None:
+            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+    def project_memory(self, memory):
+        """Per-layer K/V projections of a memory (constant across greedy steps)."""
+        return [layer.multihead_attn.project_memory(memory) for layer in self.layers]
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        if memory_mask is not None:
+            raise NotImplementedError("memory_mask is not used on the CaSE path")
+        tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
+        mv = None if memory_key_padding_mask is None else ~memory_key_padding_mask
+        y = self.forward_batch_first(tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), tv, mv,
+                                     causal=is_causal_mask(tgt_mask))
+        return y.transpose(0, 1), None, None

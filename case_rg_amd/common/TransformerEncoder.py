@@ -1,0 +1,70 @@
+"""Encoder layer / stack on the HIP path (reference: common/TransformerEncoder.py:19-77, :82-123).
+
+Layer arithmetic (note the residuals are taken from the *normed* tensors, :66-75):
+    s = LN1(x);  s = s + drop(MHA(s));  s = LN2(s);  s = s + drop(W2 drop(act(W1 s)))
+realised as: LayerNorm kernel -> QKV GEMM -> attention core -> out-proj GEMM (+dropout +residual in the
+epilogue) -> LayerNorm kernel -> FFN GEMM pair (bias+activation+dropout / bias+dropout+residual epilogues).
+"""
+import copy
+
+import torch.nn as nn
+
+from .. import config, ops
+from .attention import MultiheadAttention, is_causal_mask
+
+
+def _check_activation(activation):
+    if activation not in ("relu", "gelu"):
+        raise RuntimeError("activation should be relu/gelu, not %s." % activation)
+    return activation
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+        self.activation = _check_activation(activation)
+
+    def forward_batch_first(self, x, valid=None, causal=False):
+        """x [N, L, E]; valid [N, L] bool (True = token)."""
+        p = config.drop_p(self.p, self.training)
+        s = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        s = self.self_attn.self_attention(s, valid, causal=causal, residual=s, p_res=self.p)
+        s = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return ops.ffn(s, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                       self.activation, p_inner=p, p_out=p, residual=s)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        """src [L, N, E] (sequence first, as the reference); src_key_padding_mask [N, L] True = pad."""
+        valid = None if src_key_padding_mask is None else ~src_key_padding_mask
+        y = self.forward_batch_first(src.transpose(0, 1).contiguous(), valid, is_causal_mask(src_mask))
+        return y.transpose(0, 1)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward_batch_first(self, x, valid=None, causal=False):
+        for layer in self.layers:
+            x = layer.forward_batch_first(x, valid, causal)
+        if self.norm is not None:
+            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+    def forward(self, src, mask=None, src_key_padding_mask=None):
+        valid = None if src_key_padding_mask is None else ~src_key_padding_mask
+        y = self.forward_batch_first(src.transpose(0, 1).contiguous(), valid, is_causal_mask(mask))
+        return y.transpose(0, 1)

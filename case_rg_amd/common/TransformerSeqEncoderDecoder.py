@@ -1,0 +1,170 @@
+"""Sequence encoder and pointer-generator decoders on the HIP path.
+
+Reference: common/TransformerSeqEncoderDecoder.py:14-45 (encoder), :47-150 (generic decoder);
+CaSE/Model.py:13-125 and Masque/Model.py:13-119 hold the two task-specific decoder variants, which share
+``PointerDecoderCore`` here.
+
+Differences from the reference that do not change results:
+  * the copy distribution is a scatter-add over the source *ids* (kernel K11) instead of a dense bmm with a
+    [B, S, V] one-hot map (15-40 GB at the BASELINE sizes); a dense map is still accepted for API compatibility;
+  * greedy decoding keeps the reference's step semantics (argmax of the last position, lowest index on ties, fixed
+    T steps) but projects each memory's K/V and additive-attention keys once instead of once per step.
+"""
+import torch
+import torch.nn as nn
+
+from .. import config, ops
+from .BilinearAttention import BilinearAttention
+from .PositionalEmbedding import PositionalEmbedding
+from .TransformerDecoder import TransformerDecoder, TransformerDecoderLayer
+from .TransformerEncoder import TransformerEncoder, TransformerEncoderLayer
+from .Utils import generate_square_subsequent_mask
+
+_generate_square_subsequent_mask = generate_square_subsequent_mask
+
+
+def _embedding(vocab, width, max_len=1000):
+    return nn.Sequential(nn.Embedding(vocab, width, padding_idx=0), PositionalEmbedding(width, dropout=0.1, max_len=max_len))
+
+
+def _embed(seq, ids, training):
+    """Fused gather * sqrt(H) + position (+dropout) through the nn.Sequential(Embedding, PositionalEmbedding) pair."""
+    table, pos = seq[0].weight, seq[1]
+    if ids.shape[-1] > pos.pe.size(0):
+        raise RuntimeError("sequence length %d exceeds max_len %d" % (ids.shape[-1], pos.pe.size(0)))
+    return ops.embed_pos(ids, table, pos.pe, p_drop=config.drop_p(pos.p, training))
+
+
+class TransformerSeqEncoder(nn.Module):
+    def __init__(self, num_layers, num_heads, src_vocab_size, hidden_size, emb_matrix=None, norm=None):
+        super().__init__()
+        if emb_matrix is not None:
+            raise NotImplementedError("pre-trained embedding matrices (GloVe) are a data-prep path, out of scope")
+        self.num_layers, self.num_heads = num_layers, num_heads
+        self.embedding = _embedding(src_vocab_size, hidden_size)
+        layer = TransformerEncoderLayer(hidden_size, nhead=num_heads, dim_feedforward=hidden_size, dropout=0.1, activation='gelu')
+        self.enc = TransformerEncoder(layer, num_layers=num_layers, norm=norm)
+
+    def forward(self, batch_numseq_seqlen):
+        """ids [B, N, L] -> (out [B, N, 1, L, H], state [B, N, 1, H])."""
+        B, N, L = batch_numseq_seqlen.shape
+        ids = batch_numseq_seqlen.reshape(B * N, L)
+        valid = ids.ne(0)
+        x = _embed(self.embedding, ids, self.training)
+        y = self.enc.forward_batch_first(x, valid)
+        state = ops.masked_mean(y, valid)
+        return y.reshape(B, N, L, -1).unsqueeze(2), state.reshape(B, N, -1).unsqueeze(2)
+
+
+class PointerDecoderCore(nn.Module):
+    """Shared machinery of the three pointer-generator decoders."""
+
+    def _build(self, num_memories, num_layers, nhead, vocab, H, query_width):
+        self.tgt_vocab_size, self.num_layers, self.hidden_size = vocab, num_layers, H
+        self.embedding = _embedding(vocab, H)
+        layer = TransformerDecoderLayer(H, nhead=nhead, dim_feedforward=H, dropout=0.1, activation='gelu')
+        self.decs = nn.ModuleList([TransformerDecoder(layer, num_layers=num_layers, norm=None) for _ in range(num_memories)])
+        self.attns = nn.ModuleList([BilinearAttention(query_width, H, H) for _ in range(num_memories)])
+
+    # ------------------------------------------------------------------------------------------
+    def _prepare(self, encode_memories, encode_masks, encode_weights, batch_size):
+        H = self.hidden_size
+        mems = [m.reshape(batch_size, -1, H) for m in encode_memories]
+        valid = [m.reshape(batch_size, -1).contiguous() for m in encode_masks]
+        weights = None if encode_weights is None else [w.reshape(batch_size, -1) for w in encode_weights]
+        return mems, valid, weights
+
+    def _memory_cache(self, mems):
+        """Step-invariant projections of the memories (cross-attention K/V per layer, additive-attention keys)."""
+        return [dict(kvs=self.decs[i].project_memory(m), uh=self.attns[i].project_keys(m)) for i, m in enumerate(mems)]
+
+    def _run_prefix(self, dec_ids, mems, valid, weights, feature, cache=None):
+        """decs[0] -> attns[0] -> decs[1] -> attns[1] (a sequential chain, CaSE/Model.py:74-83)."""
+        dec_in = _embed(self.embedding, dec_ids, self.training)
+        tgt_valid = dec_ids.ne(0)
+        x = dec_in
+        ctxs, copies = [], []
+        for i, mem in enumerate(mems):
+            c = None if cache is None else cache[i]
+            x = self.decs[i].forward_batch_first(x, mem, tgt_valid, valid[i], causal=True,
+                                                 memory_kvs=None if c is None else c["kvs"])
+            q = x if feature is None else torch.cat([x, feature], dim=-1)
+            ctx, p = self.attns[i].attend(q, mem, mem, row_valid=tgt_valid, col_valid=valid[i],
+                                          uh=None if c is None else c["uh"])
+            ctxs.append(ctx)
+            if weights is not None:
+                p = weights[i].unsqueeze(1) * p
+                p = p / (1e-8 + p.sum(dim=-1, keepdim=True))
+            copies.append(p)
+        return dec_in, x, ctxs, copies
+
+    def _generate(self, gen_in, hidden_drop):
+        """gen = softmax(W_v (drop(W_h x + b)))  -- f32 logits and probabilities (K10)."""
+        h = ops.linear(gen_in, self.gen[0].weight, self.gen[0].bias, p_drop=config.drop_p(hidden_drop, self.training))
+        logits = ops.linear(h, self.gen[-2].weight, None, out_dtype=torch.float32)
+        return ops.masked_softmax(logits)
+
+    def _mix(self, dec_out, ctxs, gen, copies, source_map):
+        """p = softmax(mix([dec_out, ctx_q, ctx_p])); dist1 = p0 * gen; dist2 = pointer mass scattered to the vocabulary."""
+        mix_in = torch.cat([dec_out] + ctxs, dim=-1)
+        pm = ops.masked_softmax(ops.linear(mix_in, self.mix.weight, self.mix.bias, out_dtype=torch.float32))
+        dist1 = pm[:, :, 0:1] * gen
+        ptr = torch.cat([pm[:, :, k + 1:k + 2] * c for k, c in enumerate(copies)], dim=-1)
+        return dist1, self._scatter(ptr, source_map, gen.shape[-1])
+
+    @staticmethod
+    def _scatter(ptr, source_map, V):
+        if source_map.dtype == torch.int64 and source_map.dim() == 2:
+            return ops.copy_scatter(source_map, ptr, V)
+        # dense [B, S, V] one-hot given by an API-compatible caller: recover the ids once, then scatter
+        return ops.copy_scatter(source_map.argmax(dim=-1), ptr * source_map.sum(dim=-1).unsqueeze(1), V)
+
+    @staticmethod
+    def _bos(batch_size, BOS, device):
+        return torch.full((batch_size, 1), BOS, dtype=torch.long, device=device)
+
+
+class TransformerSeqDecoder(PointerDecoderCore):
+    """Generic multi-memory decoder (reference: common/TransformerSeqEncoderDecoder.py:47-150)."""
+
+    def __init__(self, num_memories, num_layers, nhead, tgt_vocab_size, hidden_size, emb_matrix=None):
+        super().__init__()
+        if emb_matrix is not None:
+            raise NotImplementedError("pre-trained embedding matrices (GloVe) are a data-prep path, out of scope")
+        H = hidden_size
+        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H)
+        self.norm = nn.LayerNorm(H)
+        self.gen = nn.Sequential(nn.Linear(2 * H, H), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))
+        self.mix = nn.Linear(H + num_memories * H, num_memories + 1)
+
+    def _step(self, dec_ids, mems, valid, weights, source_map, cache=None):
+        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, None, cache)
+        dec_out = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        gen = self._generate(torch.cat([dec_in, dec_out], dim=-1), 0.0)
+        d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
+        return dec_out, gen, d1 + d2
+
+    def _source(self, source_maps):
+        return torch.cat(source_maps, dim=-2 if source_maps[0].dim() == 3 else -1)
+
+    def forward(self, encode_memories, BOS, UNK, source_maps, encode_masks=None, encode_weights=None,
+                groundtruth_index=None, init_decoder_state=None, max_target_length=None):
+        source_map = self._source(source_maps) if isinstance(source_maps, (list, tuple)) else source_maps
+        B = source_map.size(0)
+        mems, valid, weights = self._prepare(encode_memories, encode_masks, encode_weights, B)
+        if max_target_length is None:
+            max_target_length = groundtruth_index.size(1)
+        bos = self._bos(B, BOS, mems[0].device)
+        if self.training and groundtruth_index is not None:
+            dec_ids = torch.cat([bos, groundtruth_index[:, :-1]], dim=-1)
+            dec_out, gen, dist = self._step(dec_ids, mems, valid, weights, source_map)
+            return dec_out, gen, dist, groundtruth_index
+        if self.training:
+            return None
+        cache = self._memory_cache(mems)
+        picked = []
+        for _ in range(max_target_length):
+            dec_ids = torch.cat([bos] + picked, dim=-1)
+            dec_out, gen, dist = self._step(dec_ids, mems, valid, weights, source_map, cache)
+            picked.append(ops.row_argmax(dist[:, -1])[0].unsqueeze(1))
+        return dec_out, gen, dist, torch.cat(picked, dim=-1)

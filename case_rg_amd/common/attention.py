@@ -1,0 +1,90 @@
+"""Multi-head attention with torch's parameter schema, computed by the HIP path.
+
+Parameters mirror ``nn.MultiheadAttention`` exactly (``in_proj_weight [3E,E]``, ``in_proj_bias [3E]``,
+``out_proj.{weight,bias}``) so reference checkpoints load and ``init_params`` works.  The
+arithmetic is: packed QKV projection (one MFMA GEMM), per-head S = QK^T / sqrt(d) with heads addressed by
+batch strides inside the packed tensor, masked softmax (+dropout on the probabilities), O = PV written
+head-interleaved, output projection with the residual and dropout folded into the GEMM epilogue.
+Batch-first [N, L, E] inside; the sequence-first wrappers live in the layer modules.
+"""
+import torch
+import torch.nn as nn
+
+from .. import config, ops
+
+
+class _OutProj(nn.Module):
+    def __init__(self, width):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(width, width))
+        self.bias = nn.Parameter(torch.zeros(width))
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise RuntimeError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.dropout = dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = _OutProj(embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.xavier_uniform_(self.out_proj.weight)
+
+    # -- batch-first cores --------------------------------------------------------------------
+    def self_attention(self, x, key_valid=None, causal=False, residual=None, p_res=0.0):
+        """x [N, L, E] -> out_proj(attention(x)) (+ dropout, + residual)."""
+        E = self.embed_dim
+        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias)
+        ctx = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, self.num_heads, self.head_dim, key_valid=key_valid, causal=causal,
+                            p_drop=config.drop_p(self.dropout, self.training))
+        return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
+                          p_drop=config.drop_p(p_res, self.training))
+
+    def project_memory(self, memory):
+        """K/V projection of a memory [N, S, E] -> packed [N, S, 2E] (cacheable across decode steps)."""
+        E = self.embed_dim
+        return ops.linear(memory, self.in_proj_weight[E:], self.in_proj_bias[E:])
+
+    def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None):
+        """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention)."""
+        E = self.embed_dim
+        q = ops.linear(x, self.in_proj_weight[:E], self.in_proj_bias[:E])
+        if kv is None:
+            kv = self.project_memory(memory)
+        ctx = ops.attention(q, kv, kv, 0, 0, E, self.num_heads, self.head_dim, key_valid=memory_valid,
+                            p_drop=config.drop_p(self.dropout, self.training))
+        return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
+                          p_drop=config.drop_p(p_res, self.training))
+
+    # -- nn.MultiheadAttention-compatible call (sequence-first) ---------------------------------
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
+        """[L, N, E] tensors; ``key_padding_mask`` True = pad.  Returns (out [Lq, N, E], None): the
+        head-averaged weights the reference discards (``[0]``) are not materialised."""
+        if key is not value:
+            raise NotImplementedError("key and value must be the same tensor (all call sites on the CaSE path)")
+        valid = None if key_padding_mask is None else ~key_padding_mask
+        q = query.transpose(0, 1).contiguous()
+        if query is key:
+            out = self.self_attention(q, valid, causal=is_causal_mask(attn_mask))
+        else:
+            if attn_mask is not None:
+                raise NotImplementedError("memory_mask is not used on the CaSE path")
+            out = self.cross_attention(q, key.transpose(0, 1).contiguous(), valid)
+        return out.transpose(0, 1), None
+
+
+def is_causal_mask(mask):
+    """None -> False; a mask built by ``generate_square_subsequent_mask`` (tagged) -> True; any other float
+    mask is checked once on the host against the causal pattern, everything else is rejected."""
+    if mask is None:
+        return False
+    if getattr(mask, "_case_causal", False):
+        return True
+    n = mask.size(0)
+    upper = torch.triu(torch.ones(n, n, dtype=torch.bool, device=mask.device), 1)
+    if mask.shape == (n, n) and bool(((mask < -1e9) == upper).all()):
+        return True
+    raise NotImplementedError("only the square subsequent (causal) attention mask is supported")
