@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- train tokens/s (query+passage) of the CaSE model on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer step of the reference's training loop (CumulativeTrainer.train_batch: forward of
+CaSE.do_train, three losses, backward, RCCL gradient all-reduce when N > 1, clip-norm 1, Adam, EMA, LR schedule)
+on one synthetic batch already resident in HBM.  Workload (BASELINE.json configs[1]): CaSE, d_model 512, 6
+encoder layers, 10 passages x 384 tokens, 64-token query, 40-token answer, batch 32 per GPU, bf16 compute,
+dropout ON (counter RNG), full-length sequences (padded-dense FLOPs == useful FLOPs).  Weak scaling:
+every rank runs the same per-GPU batch; value = N * B * (Lq + P*Lp) * K / max-over-ranks time.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel family (the bf16 MFMA GEMM instantiation with the largest total time): algorithmic
+                FLOPs per launch / average launch duration, both measured live with HIP events on the launch stream
+                over one instrumented step after the timed region; peak = 2516.6 TFLOP/s dense bf16.
+  cpu_baseline  the CPU oracle (a port of the reference, oracle/) timed on this host's cores on a bounded sample
+                (one training step at batch 1 of the same shapes), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2516.6  # 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE cfg 2: 32)")
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--enc-layers", type=int, default=6, help="BASELINE cfg 2 says 6; the reference hard-codes 3")
+    ap.add_argument("--passages", type=int, default=10)
+    ap.add_argument("--passage-len", type=int, default=384)
+    ap.add_argument("--query-len", type=int, default=64)
+    ap.add_argument("--answer-len", type=int, default=40)
+    ap.add_argument("--vocab", type=int, default=30522)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--model", default="case", choices=["case", "masque"])
+    return ap.parse_args()
+
+
+def forward_flops(a):
+    """Algorithmic padded-dense forward FLOPs of one batch (2 x MACs of the GEMM-like terms; SURVEY 8d model)."""
+    B, P, Lp, Lq, T, H, V = a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.hidden, a.vocab
+    S = P * Lp
+
+    def enc_layer(L, E):  # QKV + out + FFN(E) GEMMs, QK^T + PV
+        return 12 * L * E * E + 4 * L * L * E
+
+    def block(L, Ein, Eout):  # QKV + out at Ein, attention at Ein, Linear(Ein->Eout), Linear(Eout->Eout)
+        return 8 * L * Ein * Ein + 4 * L * L * Ein + 2 * L * Ein * Eout + 2 * L * Eout * Eout
+
+    enc = a.enc_layers * (P * enc_layer(Lp, H) + enc_layer(Lq, H))
+    inter = P * 10 * Lp * Lq * H
+    sel_p = P * (block(Lp, 5 * H, H) + 4 * block(Lp, H, H))
+    sel_q = block(Lq, 5 * H, H) + 2 * block(Lq, H, H)
+    total = enc + inter + sel_p + sel_q
+    if a.model == "case":
+        total += inter + P * (block(Lp, 5 * H, H) + 2 * block(Lp, H, H)) + block(Lq, 5 * H, H) + block(Lq, H, H)
+
+    def dec_stack(Sm):  # 4 layers: self-attn, cross-attn (K/V projection of the memory dominates), FFN
+        per = 8 * T * H * H + 4 * T * T * H + 4 * T * H * H + 4 * Sm * H * H + 4 * T * Sm * H + 4 * T * H * H
+        return 4 * per
+
+    dec = dec_stack(Lq) + dec_stack(S)
+    additive = 2 * (S + Lq) * H * H + 2 * T * (S + Lq) * H  # key projection + tanh scores
+    gen = 2 * T * 3 * H * H + 2 * T * H * V
+    return B * (total + dec + additive + gen)
+
+
+def build(a, device):
+    import case_rg_amd
+    from case_rg_amd.common.CumulativeTrainer import CumulativeTrainer, init_params
+    from case_rg_amd.common.schedule import get_cosine_with_hard_restarts_schedule_with_warmup
+    from case_rg_amd.common.Utils import init_seed
+    from case_rg_amd.utils import make_vocab, synth_batch
+
+    case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    case_rg_amd.set_dropout(True)
+    init_seed(123456)  # the reference's seed (CaSE/Run.py:92)
+    v2i, i2v = make_vocab(a.vocab)
+    if a.model == "case":
+        from case_rg_amd.CaSE.Model import CaSE
+        model = CaSE(4, a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
+    else:
+        from case_rg_amd.Masque.Model import Masque
+        model = Masque(a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
+    init_params(model)
+    trainer = CumulativeTrainer(model, None, None, device.index, a.gpus)
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4)  # CaSE/Run.py:27
+    sched = get_cosine_with_hard_restarts_schedule_with_warmup(opt, 2000, 100000)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    batch = synth_batch(a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=123456 + rank,
+                        ragged=False, model=a.model)
+    batch = {k: v.to(device) for k, v in batch.items()}
+    trainer.model.train()
+    return trainer, opt, sched, batch
+
+
+def roofline_step(a, trainer, opt, sched, batch):
+    """One extra training step with a HIP event pair around every GEMM launch (on the launch stream)."""
+    from case_rg_amd import ops
+    records = []
+    raw = ops.gemm
+
+    def timed_gemm(A_, B_, C_, M, N, K, *args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = raw(A_, B_, C_, M, N, K, *args, **kw)
+        e1.record()
+        key = "gemm_kernel<%s,%s,%s,%s>" % ("bf16" if A_.dtype == torch.bfloat16 else "f32", "bf16" if C_.dtype == torch.bfloat16 else "f32",
+                                            "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
+        records.append((key, 2.0 * M * N * K * kw.get("batch1", 1) * kw.get("batch2", 1), e0, e1))
+        return out
+
+    ops.gemm = timed_gemm
+    try:
+        trainer.train_batch(0, dict(batch), "train", opt, sched)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = raw
+    fam = {}
+    for key, flops, e0, e1 in records:
+        f = fam.setdefault(key, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    key, (flops, secs, n) = max(fam.items(), key=lambda kv: kv[1][1])
+    achieved = flops / secs / 1e12
+    all_flops, all_secs = sum(v[0] for v in fam.values()), sum(v[1] for v in fam.values())
+    return {"bound": "mfma", "kernel": key, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+            "avg_launch_ms": round(secs / n * 1e3, 4), "flops_per_launch": flops / n,
+            "all_gemm_tflops": round(all_flops / all_secs / 1e12, 1), "all_gemm_ms_per_step": round(all_secs * 1e3, 2),
+            "families": {k: {"ms": round(v[1] * 1e3, 2), "tflops": round(v[0] / v[1] / 1e12, 1), "launches": v[2]} for k, v in fam.items()}}
+
+
+def cpu_baseline(a):
+    """The CPU oracle (fp32 port of the reference) on this host: one training step at batch 1, same shapes."""
+    import oracle
+    from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+    v2i, i2v = make_vocab(a.vocab)
+    if a.model == "case":
+        m = oracle.CaSE(4, a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
+    else:
+        m = oracle.Masque(a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
+    fill_params(m, 1).train()
+    b = synth_batch(1, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
+    opt = torch.optim.Adam(m.parameters(), lr=2.5e-4)
+    t0 = time.time()
+    losses = m(dict(b), method="train")
+    sum(l.mean() for l in losses).backward()
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 1)
+    opt.step()
+    dt = time.time() - t0
+    tokens = a.query_len + a.passages * a.passage_len
+    return {"value": round(tokens / dt, 1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 training step (fwd+bwd+clip+Adam) of the fp32 CPU oracle at batch 1, same shapes, %.1f s" % dt}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+    rank = dist.get_rank() if world > 1 else 0
+    trainer, opt, sched, batch = build(a, device)
+
+    def step():
+        return trainer.train_batch(0, dict(batch), "train", opt, sched)
+
+    for _ in range(a.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tokens_per_step = world * a.batch * (a.query_len + a.passages * a.passage_len)
+    value = tokens_per_step * a.steps / elapsed
+    fwd = forward_flops(a)
+    out = {
+        "metric": "train tokens/sec (query+passage) CaSE model" if a.model == "case" else "train tokens/sec (query+passage) Masque model",
+        "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "%s train step fwd+bwd+allreduce+clip+Adam+EMA, d_model=%d, %d encoder layers, %d passages x %d tok, "
+                               "query %d, answer %d, vocab %d, per-GPU batch %d, dropout on" % (
+                                   "CaSE" if a.model == "case" else "Masque", a.hidden, a.enc_layers, a.passages, a.passage_len,
+                                   a.query_len, a.answer_len, a.vocab, a.batch),
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world,
+                   "algorithmic_tflop_per_step": round(3 * fwd * world / 1e12, 2)},
+        "step_mfma_frac": round(3 * fwd / (elapsed / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "last_losses": [round(x, 4) for x in losses],
+    }
+    if rank == 0 and not a.no_roofline:
+        out["roofline"] = roofline_step(a, trainer, opt, sched, batch)
+    elif world > 1 and not a.no_roofline:
+        step()  # keep the ranks in lock-step with rank 0's instrumented step (it contains an all-reduce)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""Single-node data parallelism: one process per GPU, gradients summed with bucketed all-reduce
+(``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the tests).
+
+The reference wraps the model in DistributedDataParallel (common/CumulativeTrainer.py:45-47).  Here the model
+stays a bare module: per-parameter post-accumulate hooks fill flat fp32 buckets in reverse registration order
+(~ the order backward produces them: decoder first, encoder last) and launch one asynchronous all-reduce per
+bucket as soon as it is complete, so communication of the decoder / block gradients overlaps the rest of
+backward (which is > 90 % of its time).  ``finish()`` waits, averages and scatters the buckets back.
+Batch items never interact in forward, so there is no other collective on the path.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, model, bucket_mb=64, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.buckets = []  # [flat buffer, [(param, offset, numel)], pending count, work handle]
+        self._slot = {}
+        if self.world == 1:
+            return
+        cap = int(bucket_mb * (1 << 20) // 4)
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                self._close_bucket(cur, cur_n)
+                cur, cur_n = [], 0
+            cur.append((p, cur_n, p.numel()))
+            cur_n += p.numel()
+        if cur:
+            self._close_bucket(cur, cur_n)
+        self.broadcast_parameters(model)
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._armed = True
+
+    def _close_bucket(self, items, numel):
+        p0 = items[0][0]
+        flat = torch.zeros(numel, dtype=torch.float32, device=p0.device)
+        idx = len(self.buckets)
+        self.buckets.append({"flat": flat, "items": items, "pending": len(items), "work": None})
+        for p, _, _ in items:
+            self._slot[id(p)] = idx
+
+    def broadcast_parameters(self, model):
+        """Rank 0's parameters and buffers become everyone's (what DDP does at wrap time)."""
+        with torch.no_grad():
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+
+    def no_sync(self, flag=True):
+        """Gradient accumulation micro-steps: skip the all-reduce (the reference does not)."""
+        self._armed = not flag
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self.buckets[self._slot[id(p)]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        flat = b["flat"]
+        for p, off, n in b["items"]:
+            flat[off:off + n].copy_(p.grad.reshape(-1)) if p.grad is not None else flat[off:off + n].zero_()
+        b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for every bucket, average, write the reduced gradients back.  Buckets whose hooks did not all fire
+        (parameters unused this step) are reduced here with zeros for the missing gradients."""
+        if self.world == 1 or not self._armed:
+            return
+        for b in self.buckets:
+            if b["work"] is None:
+                self._launch(b)
+        for b in self.buckets:
+            b["work"].wait()
+            flat = b["flat"].div_(self.world)
+            for p, off, n in b["items"]:
+                if p.grad is None:
+                    p.grad = flat[off:off + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[off:off + n].view_as(p))
+            b["work"], b["pending"] = None, len(b["items"])
