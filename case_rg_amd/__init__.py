@@ -37,9 +37,10 @@ def install_dropin():
     """Alias this package's ``common`` / ``CaSE`` / ``Masque`` as top-level modules so the reference's launch
     scripts (``from CaSE.Model import *``, ``from common.CumulativeTrainer import *``) resolve to the HIP path."""
     import importlib
+    import pkgutil
     for name in ("common", "CaSE", "Masque"):
         pkg = importlib.import_module(__name__ + "." + name)
         _sys.modules[name] = pkg
-        for sub in list(_sys.modules):
-            if sub.startswith(__name__ + "." + name + "."):
-                _sys.modules[sub[len(__name__) + 1:]] = _sys.modules[sub]
+        for info in pkgutil.iter_modules(pkg.__path__):
+            sub = importlib.import_module("%s.%s.%s" % (__name__, name, info.name))
+            _sys.modules["%s.%s" % (name, info.name)] = sub

@@ -6,6 +6,8 @@ loudly, and every call that returns a negative code raises RuntimeError(case_las
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first: libcase_hip.so must bind to the HIP runtime instance torch has already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcase_hip.so")
 

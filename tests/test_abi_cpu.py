@@ -1,0 +1,84 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads and exports exactly the symbols that
+include/case_hip.h declares; the ctypes table mirrors the header; the product refuses to run without a GPU
+instead of falling back.  No compute is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "case_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(?:int|const char\*)\s+(case_\w+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    from case_rg_amd import _abi
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libcase_hip.so does not export %s" % n
+
+
+def test_ctypes_table_matches_header():
+    from case_rg_amd import _abi
+    assert set(_abi.SIGNATURES) | {"case_version", "case_last_error"} == _declared()
+    text = open(HEADER).read()
+    for name, args in _abi.SIGNATURES.items():
+        proto = re.search(r"\b%s\s*\((.*?)\);" % name, text, flags=re.S).group(1)
+        assert len([a for a in proto.split(",") if a.strip()]) == len(args), "argument count of %s" % name
+
+
+def test_struct_layouts_match_header_field_order():
+    from case_rg_amd import _abi
+    text = open(HEADER).read()
+    for cname, struct in (("CaseGemmDesc", _abi.GemmDesc), ("CaseSoftmaxDesc", _abi.SoftmaxDesc)):
+        body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} %s;" % cname, text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                fields += [f.strip() for f in decl.split(None, 1)[1].split(",")]
+        assert fields == [f[0] for f in struct._fields_], cname
+
+
+def test_version_and_error_string():
+    from case_rg_amd import _abi
+    assert _abi.lib.case_version() >= 100
+    assert isinstance(_abi.lib.case_last_error(), bytes)
+
+
+def test_argument_validation_happens_before_any_launch():
+    """A null/empty problem is rejected on the host side of the ABI (no GPU needed to see the error path)."""
+    from case_rg_amd import _abi
+    d = _abi.GemmDesc()
+    with pytest.raises(RuntimeError, match="case_gemm"):
+        _abi.call("case_gemm", d, None, None, None, None, None, None, None, None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_cpu_fallback():
+    from case_rg_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    from case_rg_amd.common.TransformerEncoder import TransformerEncoderLayer
+    layer = TransformerEncoderLayer(32, 8, 32, activation="gelu")
+    with pytest.raises(RuntimeError, match="GPU only"):
+        layer(torch.zeros(5, 2, 32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "case_rg_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), "%s imports the oracle" % f

@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: world_size-2 ``gloo`` processes drive ``case_rg_amd.parallel.GradSync`` (the bucketed
+all-reduce the trainer uses on RCCL) around the CPU oracle model.  DP-averaged gradients must equal the mean of
+the per-shard gradients computed in one process, parameters must be broadcast from rank 0, and gradient
+accumulation must reduce only on the boundary step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model():
+    import oracle
+    from case_rg_amd.utils import make_vocab
+    v2i, i2v = make_vocab(150)
+    return oracle.Masque(5, i2v, v2i, 32, enc_layers=1, dec_layers=1)
+
+
+def _shard(rank):
+    from case_rg_amd.utils import synth_batch
+    return synth_batch(2, 2, 10, 6, 5, 150, seed=100 + rank, model="masque")
+
+
+def _grads(model, batch):
+    model.zero_grad()
+    losses = model(dict(batch), method="train")
+    sum(l.mean() for l in losses).backward()
+    return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from case_rg_amd.parallel import GradSync
+        from case_rg_amd.utils import fill_params
+        model = fill_params(_model(), 40 + rank).train()  # ranks start different: broadcast must fix that
+        sync = GradSync(model, bucket_mb=0.05)             # tiny buckets -> many buckets, async launches
+        assert len(sync.buckets) > 3
+        # accumulation micro-step: no communication, gradients stay local
+        sync.no_sync(True)
+        local = _grads(model, _shard(rank))
+        sync.finish()
+        assert all(torch.equal(local[n], p.grad) for n, p in model.named_parameters())
+        # boundary step: reduce (grads accumulate on top of the micro-step, as CumulativeTrainer does)
+        sync.no_sync(False)
+        losses = model(dict(_shard(rank)), method="train")
+        sum(l.mean() for l in losses).backward()
+        sync.finish()
+        torch.save({"grads": {n: p.grad for n, p in model.named_parameters()},
+                    "params": {n: p.detach() for n, p in model.named_parameters()}}, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradsync_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    from case_rg_amd.utils import fill_params
+    ref = fill_params(_model(), 40).train()  # rank 0's parameters
+    for n, p in ref.named_parameters():
+        assert torch.equal(r0["params"][n], p) and torch.equal(r1["params"][n], p), "broadcast of " + n
+    g0, g1 = _grads(ref, _shard(0)), _grads(ref, _shard(1))
+    for n in g0:
+        want = 2.0 * 0.5 * (g0[n] + g1[n])  # micro-step + boundary step, each averaged over 2 ranks
+        assert torch.allclose(r0["grads"][n], want, rtol=1e-5, atol=1e-7), n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), "ranks disagree on " + n

@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: batch schema, deterministic filler, module-attribute graph / state_dict
+schema, helpers restated from common/Utils.py, LR schedule, dropout counter bookkeeping."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from case_rg_amd import config
+from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+
+
+def test_synth_batch_follows_the_collate_schema():
+    b = synth_batch(3, 4, 16, 8, 6, 300, seed=1, model="case")
+    assert b["query"].shape == (3, 1, 8) and b["passage"].shape == (3, 4, 16)
+    assert b["source_map"].shape == (3, 8 + 4 * 16)
+    assert torch.equal(b["source_map"], torch.cat([b["query"].reshape(3, -1), b["passage"].reshape(3, -1)], 1))
+    assert (b["query"][:, 0, 0] == 101).all() and (b["passage"][:, :, 0] == 101).all()  # [CLS] first
+    assert b["token_label"].shape == (3, 4, 16) and b["token_weight"].dtype == torch.float32
+    assert ((b["token_label"] == 0) | (b["passage"] != 0)).all()
+    last = b["response"].ne(0).sum(1) - 1
+    assert (b["response"][torch.arange(3), last] == 2).all()  # ends with EOS
+    assert "token_label" not in synth_batch(2, 2, 8, 4, 4, 300, model="masque")
+    full = synth_batch(2, 3, 16, 8, 6, 300, ragged=False)
+    assert (full["passage"] != 0).all() and (full["query"] != 0).all() and full["response"].shape == (2, 6)
+    again = synth_batch(3, 4, 16, 8, 6, 300, seed=1, model="case")
+    assert all(torch.equal(b[k], again[k]) for k in b)
+
+
+def test_filler_is_name_keyed_and_alias_independent():
+    v2i, i2v = make_vocab(200)
+    a = fill_params(oracle.CaSE(4, 6, i2v, v2i, 32), 9)
+    import case_rg_amd
+    p = fill_params(case_rg_amd.namespace().CaSE(4, 6, i2v, v2i, 32), 9)
+    sa, sp = a.state_dict(), p.state_dict()
+    assert set(sa) == set(sp) and len(sa) == 1301
+    for k in sa:
+        assert torch.equal(sa[k], sp[k]), k
+    # shared encoder: every alias sees the same tensor
+    assert sp["query_encoder.embedding.0.weight"].data_ptr() == sp["response_generation.span_extraction.passage_selection.passage_encoder.embedding.0.weight"].data_ptr()
+    other = fill_params(oracle.CaSE(4, 6, i2v, v2i, 32), 10)
+    assert not torch.equal(other.state_dict()["passage_selection.scorer.weight"], sa["passage_selection.scorer.weight"])
+
+
+def test_masque_schema_counts():
+    import case_rg_amd
+    v2i, i2v = make_vocab(200)
+    m = case_rg_amd.namespace().Masque(6, i2v, v2i, 32)
+    assert len(m.state_dict()) == 663 and len(list(m.parameters())) == 296
+    assert hasattr(m, "do_infer") and hasattr(m, "do_ps_train")
+
+
+def test_utils_restatements():
+    from case_rg_amd.common import Utils
+    from case_rg_amd.common.Constants import BOS_WORD, EOS_WORD, PAD_WORD, UNK_WORD
+    v2i, i2v = make_vocab(200)
+    ids = torch.tensor([[v2i[BOS_WORD], 110, 111, v2i[EOS_WORD], 112], [v2i[PAD_WORD], v2i[EOS_WORD], 5, 6, 7]])
+    assert Utils.to_sentence(ids, i2v) == [["tok110", "tok111"], [UNK_WORD]]
+    assert oracle.models.ids_to_tokens(ids, i2v) == Utils.to_sentence(ids, i2v)
+    sents = [list("abcabc"), list("abcd")]
+    Utils.remove_duplicate(sents)
+    assert sents == [list("abc"), list("abcd")]
+    assert Utils.neginf(torch.float32) == -1e20 and Utils.neginf(torch.float16) == -65504
+    onehot = Utils.build_map(torch.tensor([[1, 3], [0, 2]]), max=4)
+    assert torch.equal(onehot, oracle.build_map(torch.tensor([[1, 3], [0, 2]]), max=4))
+
+
+def test_positional_table_matches_oracle():
+    from case_rg_amd.common.PositionalEmbedding import sinusoid_table
+    assert torch.allclose(sinusoid_table(50, 32), oracle.sinusoid_table(50, 32), atol=0, rtol=0)
+
+
+def test_schedule_definition():
+    from case_rg_amd.common.schedule import get_cosine_with_hard_restarts_schedule_with_warmup
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = get_cosine_with_hard_restarts_schedule_with_warmup(opt, 10, 110)
+    lrs = []
+    for _ in range(111):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert lrs[0] == 0.0 and lrs[5] == pytest.approx(0.5) and lrs[10] == pytest.approx(1.0)
+    assert lrs[60] == pytest.approx(0.5 * (1 + math.cos(math.pi * 0.5))) and lrs[110] == 0.0
+
+
+def test_dropout_counter_bookkeeping():
+    config.manual_seed(5)
+    s0, o0 = config.next_rng(100)
+    s1, o1 = config.next_rng(7)
+    assert (s0, o0, s1, o1) == (5, 0, 5, 100)
+    config.set_dropout(False)
+    assert config.drop_p(0.1, True) == 0.0
+    config.set_dropout(True)
+    assert config.drop_p(0.1, True) == pytest.approx(0.1) and config.drop_p(0.1, False) == 0.0
+    config.set_dropout(False)
+    with pytest.raises(ValueError):
+        config.set_compute_dtype(torch.float16)
+
+
+def test_install_dropin_aliases_reference_import_paths():
+    import sys
+    import case_rg_amd
+    saved = {k: sys.modules.get(k) for k in ("common", "CaSE", "Masque")}
+    try:
+        case_rg_amd.install_dropin()
+        from CaSE.Model import CaSE  # noqa: F401  (what CaSE/Run.py does)
+        from common.CumulativeTrainer import CumulativeTrainer, init_params  # noqa: F401
+        from Masque.Model import Masque  # noqa: F401
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                for name in [n for n in sys.modules if n == k or n.startswith(k + ".")]:
+                    del sys.modules[name]
+            else:
+                sys.modules[k] = v
+
+
+def test_bench_flop_model_matches_the_survey():
+    """20.06 TFLOP (3 encoder layers) / 21.53 TFLOP (6) forward at cfg 2."""
+    import argparse
+    import bench
+    a = argparse.Namespace(batch=32, passages=10, passage_len=384, query_len=64, answer_len=40, hidden=512, vocab=30522,
+                           enc_layers=3, model="case")
+    assert bench.forward_flops(a) / 1e12 == pytest.approx(20.06, rel=0.03)
+    a.enc_layers = 6
+    assert bench.forward_flops(a) / 1e12 == pytest.approx(21.53, rel=0.03)
