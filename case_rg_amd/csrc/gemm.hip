@@ -52,42 +52,52 @@ struct Args {
 // ---- global -> register staging -------------------------------------------------------------
 // One 16-byte chunk = EPT elements along the operand's contiguous axis.  `lead` indexes the strided
 // axis (row for k-contiguous operands, k for k-major ones), `c0` the first element on the contiguous axis.
-template <typename T>
+template <typename T, bool VEC>
 __device__ __forceinline__ u32x4 load_chunk(const T* __restrict__ base, int64_t ld, int64_t lead, int64_t lead_max,
-                                            int64_t c0, int64_t c_max, bool vec) {
+                                            int64_t c0, int64_t c_max, bool& ok) {
   constexpr int EPT = 16 / sizeof(T);
-  u32x4 r = {0u, 0u, 0u, 0u};
-  if (lead >= lead_max || c0 >= c_max) return r;
-  const T* p = base + lead * ld + c0;
-  if (vec && c0 + EPT <= c_max) return *reinterpret_cast<const u32x4*>(p);
-  T tmp[EPT];
+  ok = lead < lead_max && c0 < c_max;
+  if constexpr (VEC) {
+    // branch-free and select-free here: an out-of-range chunk reads element (0,0); it is zeroed when the registers are
+    // written to LDS (stage_store), so the eight loads of a tile issue back to back and stay in flight under the MFMAs
+    // (a guarded load makes hipcc branch and wait vmcnt(0) per chunk; a select here would pull the wait up to the load)
+    return *reinterpret_cast<const u32x4*>(base + (ok ? lead * ld + c0 : 0));
+  } else {
+    T tmp[EPT];
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) tmp[e] = (c0 + e < c_max) ? p[e] : T(0);
-  return *reinterpret_cast<u32x4*>(tmp);
-}
-
-template <typename T, bool KMAJOR>
-__device__ __forceinline__ void stage_load(u32x4 (&regs)[4], const T* __restrict__ base, int64_t ld, int64_t mn0,
-                                           int64_t mn_max, int64_t k0, int64_t k_max, bool vec) {
-  constexpr int EPT = 16 / sizeof(T);
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + i * NTHREADS;
-    if constexpr (!KMAJOR) {
-      const int row = c >> 3, kc = c & 7;
-      regs[i] = load_chunk<T>(base, ld, mn0 + row, mn_max, k0 + kc * EPT, k_max, vec);
-    } else {
-      constexpr int CPR = BM * sizeof(T) / 16;  // chunks per k-row: 16 (bf16) / 32 (f32)
-      const int krow = c / CPR, nc = c % CPR;
-      regs[i] = load_chunk<T>(base, ld, k0 + krow, k_max, mn0 + nc * EPT, mn_max, vec);
-    }
+    for (int e = 0; e < EPT; ++e) tmp[e] = (ok && c0 + e < c_max) ? base[lead * ld + c0 + e] : T(0);
+    ok = true;
+    return *reinterpret_cast<u32x4*>(tmp);
   }
 }
 
-template <typename T, bool KMAJOR>
-__device__ __forceinline__ void stage_store(const u32x4 (&regs)[4], char* lds) {
+template <typename T, bool KMAJOR, bool VEC>
+__device__ __forceinline__ unsigned stage_load(u32x4 (&regs)[4], const T* __restrict__ base, int64_t ld, int64_t mn0,
+                                               int64_t mn_max, int64_t k0, int64_t k_max) {
+  constexpr int EPT = 16 / sizeof(T);
   const int tid = threadIdx.x;
+  unsigned okmask = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * NTHREADS;
+    bool ok;
+    if constexpr (!KMAJOR) {
+      const int row = c >> 3, kc = c & 7;
+      regs[i] = load_chunk<T, VEC>(base, ld, mn0 + row, mn_max, k0 + kc * EPT, k_max, ok);
+    } else {
+      constexpr int CPR = BM * sizeof(T) / 16;  // chunks per k-row: 16 (bf16) / 32 (f32)
+      const int krow = c / CPR, nc = c % CPR;
+      regs[i] = load_chunk<T, VEC>(base, ld, k0 + krow, k_max, mn0 + nc * EPT, mn_max, ok);
+    }
+    okmask |= (ok ? 1u : 0u) << i;
+  }
+  return okmask;
+}
+
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void stage_store(const u32x4 (&regs)[4], unsigned okmask, char* lds) {
+  const int tid = threadIdx.x;
+  const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + i * NTHREADS;
@@ -98,7 +108,7 @@ __device__ __forceinline__ void stage_store(const u32x4 (&regs)[4], char* lds) {
       constexpr int CPR = BM * sizeof(T) / 16;
       off = (c / CPR) * KM<T>::row_stride + (c % CPR) * 16;
     }
-    *reinterpret_cast<u32x4*>(lds + off) = regs[i];
+    *reinterpret_cast<u32x4*>(lds + off) = ((okmask >> i) & 1u) ? regs[i] : z;
   }
 }
 
@@ -218,7 +228,7 @@ struct Epilogue {
   }
 };
 
-template <typename T, typename OutT, bool AK, bool BK_>
+template <typename T, typename OutT, bool AK, bool BK_, bool VEC>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g, const int epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKE = ROWB / sizeof(T);  // K elements per tile
@@ -256,24 +266,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g, const i
 
   if (kt_begin < kt_end) {
     u32x4 ra[4], rb[4];
-    stage_load<T, AK>(ra, A, g.lda, m0, g.M, (int64_t)kt_begin * BKE, g.K, g.vec_a);
-    stage_load<T, BK_>(rb, B, g.ldb, n0, g.N, (int64_t)kt_begin * BKE, g.K, g.vec_b);
-    stage_store<T, AK>(ra, smem);
-    stage_store<T, BK_>(rb, smem + OP_BYTES);
+    unsigned oka = stage_load<T, AK, VEC>(ra, A, g.lda, m0, g.M, (int64_t)kt_begin * BKE, g.K);
+    unsigned okb = stage_load<T, BK_, VEC>(rb, B, g.ldb, n0, g.N, (int64_t)kt_begin * BKE, g.K);
+    stage_store<T, AK>(ra, oka, smem);
+    stage_store<T, BK_>(rb, okb, smem + OP_BYTES);
     __syncthreads();
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const bool more = kt + 1 < kt_end;
       if (more) {
-        stage_load<T, AK>(ra, A, g.lda, m0, g.M, (int64_t)(kt + 1) * BKE, g.K, g.vec_a);
-        stage_load<T, BK_>(rb, B, g.ldb, n0, g.N, (int64_t)(kt + 1) * BKE, g.K, g.vec_b);
+        oka = stage_load<T, AK, VEC>(ra, A, g.lda, m0, g.M, (int64_t)(kt + 1) * BKE, g.K);
+        okb = stage_load<T, BK_, VEC>(rb, B, g.ldb, n0, g.N, (int64_t)(kt + 1) * BKE, g.K);
       }
       const char* la = smem + cur * STAGE_BYTES;
       mma_tile<T, AK, BK_>(acc, la, la + OP_BYTES, wr, wc);
       if (more) {
         char* nx = smem + (cur ^ 1) * STAGE_BYTES;
-        stage_store<T, AK>(ra, nx);
-        stage_store<T, BK_>(rb, nx + OP_BYTES);
+        stage_store<T, AK>(ra, oka, nx);
+        stage_store<T, BK_>(rb, okb, nx + OP_BYTES);
       }
       __syncthreads();
       cur ^= 1;
@@ -303,20 +313,26 @@ template <typename T, typename OutT>
 int launch(const Args& a, int epi, bool ak, bool bk, hipStream_t s) {
   const dim3 grid(a.nwg), block(NTHREADS);
   const size_t lds = 2 * STAGE_BYTES;
-#define GO(AKV, BKV)                                                                                       \
+#define GO1(AKV, BKV, VV)                                                                                  \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, OutT, AKV, BKV>),                  \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, OutT, AKV, BKV, VV>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       attr_set = true;                                                                                     \
     }                                                                                                      \
-    hipLaunchKernelGGL((gemm_kernel<T, OutT, AKV, BKV>), grid, block, lds, s, a, epi);                     \
+    hipLaunchKernelGGL((gemm_kernel<T, OutT, AKV, BKV, VV>), grid, block, lds, s, a, epi);                 \
+  } while (0)
+#define GO(AKV, BKV)                                                                                       \
+  do {                                                                                                     \
+    if (a.vec_a && a.vec_b) GO1(AKV, BKV, true);                                                           \
+    else GO1(AKV, BKV, false);                                                                             \
   } while (0)
   if (!ak && !bk) GO(false, false);
   else if (!ak && bk) GO(false, true);
   else if (ak && !bk) GO(true, false);
   else GO(true, true);
+#undef GO1
 #undef GO
   return case_check_launch("case_gemm");
 }
