@@ -30,6 +30,11 @@ class SoftmaxDesc(C.Structure):
                 ("out_dtype", i32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [(n, i64) for n in ("N", "heads", "Lq", "Lk", "head_dim", "ldq", "ldk", "ldv", "sq", "sk", "sv", "ldo", "so")] + \
+               [("causal", i32), ("scale", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
+
+
 # name -> argument types (all return int); mirrors include/case_hip.h one to one
 SIGNATURES = {
     "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
@@ -40,6 +45,10 @@ SIGNATURES = {
     "case_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_softmax_fwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr, ptr, ptr],
     "case_softmax_bwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr],
+    "case_attention_supported": [i64],
+    "case_attention_fwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_attention_bwd_supported": [i64],
+    "case_attention_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],
     "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],
     "case_mask_rows": [ptr, ptr, ptr, i64, i64, i32, ptr],

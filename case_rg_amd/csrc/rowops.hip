@@ -92,6 +92,235 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- vectorised LayerNorm: one wave per row, the row lives in registers (16-byte loads, <= 8 vectors per lane) ------
+constexpr int LNV_MAX = 8;
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ x2,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int64_t rows, int64_t cols, float eps) {
+  constexpr int E = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    float v[NV][E];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = ((int64_t)i * 64 + lane) * E;
+      if (c < cols) {
+        Vec16<T>::load(x + r * cols + c, v[i]);
+        if (x2) {
+          float w[E];
+          Vec16<T>::load(x2 + r * cols + c, w);
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[i][e] += w[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) s += v[i][e];
+      }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (((int64_t)i * 64 + lane) * E < cols) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) q += (v[i][e] - mu) * (v[i][e] - mu);
+      }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = ((int64_t)i * 64 + lane) * E;
+      if (c < cols) {
+        float g[E], b[E], o[E];
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+          const float4 gg = *reinterpret_cast<const float4*>(gamma + c + e), bb = *reinterpret_cast<const float4*>(beta + c + e);
+          g[e] = gg.x; g[e + 1] = gg.y; g[e + 2] = gg.z; g[e + 3] = gg.w;
+          b[e] = bb.x; b[e + 1] = bb.y; b[e + 2] = bb.z; b[e + 3] = bb.w;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        Vec16<T>::store(y + r * cols + c, o);
+      }
+    }
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ x2, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         T* __restrict__ dx, float* __restrict__ d_gamma,
+                                                         float* __restrict__ d_beta, int64_t rows, int64_t cols) {
+  constexpr int E = Vec16<T>::N;
+  extern __shared__ float part[];  // [2][cols] partial d_gamma / d_beta of waves 1..3, added to wave 0's
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wid, nwaves = (int64_t)gridDim.x * 4;
+  float ag[NV][E], ab[NV][E], g[NV][E];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = ((int64_t)i * 64 + lane) * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      ag[i][e] = ab[i][e] = 0.f;
+      g[i][e] = c < cols ? gamma[c + e] : 0.f;
+    }
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    float xh[NV][E], gy[NV][E];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = ((int64_t)i * 64 + lane) * E;
+      if (c < cols) {
+        float d[E];
+        Vec16<T>::load(x + r * cols + c, xh[i]);
+        if (x2) {
+          float w[E];
+          Vec16<T>::load(x2 + r * cols + c, w);
+#pragma unroll
+          for (int e = 0; e < E; ++e) xh[i][e] += w[e];
+        }
+        Vec16<T>::load(dy + r * cols + c, d);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          xh[i][e] = (xh[i][e] - mu) * rs;
+          gy[i][e] = d[e] * g[i][e];
+          s1 += gy[i][e];
+          s2 += gy[i][e] * xh[i][e];
+          ag[i][e] += d[e] * xh[i][e];
+          ab[i][e] += d[e];
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)cols, m2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = ((int64_t)i * 64 + lane) * E;
+      if (c < cols) {
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
+        Vec16<T>::store(dx + r * cols + c, o);
+      }
+    }
+  }
+  // workgroup reduction of the column partials through LDS, then one atomic per column per workgroup
+  for (int w = 1; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int64_t c = ((int64_t)i * 64 + lane) * E;
+        if (c < cols) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            part[c + e] = ag[i][e];
+            part[cols + c + e] = ab[i][e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int64_t c = ((int64_t)i * 64 + lane) * E;
+        if (c < cols) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            ag[i][e] += part[c + e];
+            ab[i][e] += part[cols + c + e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wid == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = ((int64_t)i * 64 + lane) * E;
+      if (c < cols) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          atomicAdd(d_gamma + c + e, ag[i][e]);
+          atomicAdd(d_beta + c + e, ab[i][e]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+bool ln_vec_ok(const void* a, const void* b, const void* c, int64_t cols) {
+  constexpr int E = Vec16<T>::N;
+  auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p % 16 == 0); };
+  return cols % E == 0 && cols <= (int64_t)LNV_MAX * 64 * E && al(a) && al(b) && al(c);
+}
+
+template <typename T>
+void ln_fwd_vec_launch(const void* x, const void* x2, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, int64_t rows, int64_t cols, float eps, hipStream_t s) {
+  constexpr int E = Vec16<T>::N;
+  const int nv = (int)((cols + 64 * E - 1) / (64 * E));
+  const int grid = grid_for(rows, 4, 1, 256 * 16);
+#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, NVV>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)x2, gamma, beta, (T*)y, mean, rstd, rows, cols, eps)
+  switch (nv) { case 1: LNF(1); break; case 2: LNF(2); break; case 3: LNF(3); break; case 4: LNF(4); break;
+                case 5: LNF(5); break; case 6: LNF(6); break; case 7: LNF(7); break; default: LNF(8); break; }
+#undef LNF
+}
+
+template <typename T>
+void ln_bwd_vec_launch(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, float* dg, float* db, int64_t rows, int64_t cols, hipStream_t s) {
+  constexpr int E = Vec16<T>::N;
+  const int nv = (int)((cols + 64 * E - 1) / (64 * E));
+  const int grid = grid_for(rows, 4, 16, 256 * 4);  // >= 16 rows per wave: column partials are reduced per workgroup
+  const size_t lds = 2 * cols * sizeof(float);
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, dg, db, rows, cols)
+  switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break;
+                case 5: LNB(5); break; case 6: LNB(6); break; case 7: LNB(7); break; default: LNB(8); break; }
+#undef LNB
+}
+
 // ---- softmax ----------------------------------------------------------------------------------
 template <int TPR>  // threads per row: 64 (wave) or 256 (workgroup)
 __device__ __forceinline__ float row_max(float v, float* red) {
@@ -212,6 +441,14 @@ extern "C" int case_layernorm_fwd(const void* x, const void* x2, const float* ga
   CASE_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && cols > 0, "case_layernorm_fwd: bad argument");
   const int grid = grid_for(rows, 1);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32 && ln_vec_ok<float>(x, x2, y, cols) && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0) {
+    ln_fwd_vec_launch<float>(x, x2, gamma, beta, y, mean, rstd, rows, cols, eps, s);
+    return case_check_launch("case_layernorm_fwd");
+  }
+  if (dtype == CASE_BF16 && ln_vec_ok<bf16_t>(x, x2, y, cols) && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0) {
+    ln_fwd_vec_launch<bf16_t>(x, x2, gamma, beta, y, mean, rstd, rows, cols, eps, s);
+    return case_check_launch("case_layernorm_fwd");
+  }
   if (dtype == CASE_F32)
     hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(LN_THREADS), 0, s, (const float*)x, (const float*)x2, gamma,
                        beta, (float*)y, mean, rstd, rows, cols, eps);
@@ -230,6 +467,14 @@ extern "C" int case_layernorm_bwd(const void* dy, const void* x, const void* x2,
                LN_THREADS * LN_MAXPT);
   const int grid = grid_for(rows, 1, 8, 256 * 2);  // few workgroups -> few atomics on d_gamma / d_beta
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32 && ln_vec_ok<float>(dy, x, dx, cols) && ln_vec_ok<float>(x2, nullptr, nullptr, cols)) {
+    ln_bwd_vec_launch<float>(dy, x, x2, gamma, mean, rstd, dx, d_gamma, d_beta, rows, cols, s);
+    return case_check_launch("case_layernorm_bwd");
+  }
+  if (dtype == CASE_BF16 && ln_vec_ok<bf16_t>(dy, x, dx, cols) && ln_vec_ok<bf16_t>(x2, nullptr, nullptr, cols)) {
+    ln_bwd_vec_launch<bf16_t>(dy, x, x2, gamma, mean, rstd, dx, d_gamma, d_beta, rows, cols, s);
+    return case_check_launch("case_layernorm_bwd");
+  }
   if (dtype == CASE_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(LN_THREADS), 0, s, (const float*)dy, (const float*)x,
                        (const float*)x2, gamma, mean, rstd, (float*)dx, d_gamma, d_beta, rows, cols);

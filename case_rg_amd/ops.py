@@ -347,38 +347,111 @@ def _attn_geometry(src, off, heads, d):
     return dict(t=src, off=off, ld=W, s1=L * W, s2=d, L=L, N=N)
 
 
+def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d):
+    if q_src.dtype != torch.bfloat16 or not A.lib.case_attention_supported(d):
+        return False
+    for t, off in ((q_src, q_off), (k_src, k_off), (v_src, v_off)):
+        if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop):
+    ad = A.AttnDesc()
+    ad.N, ad.heads, ad.Lq, ad.Lk, ad.head_dim = N, heads, Lq, Lk, d
+    ad.ldq, ad.ldk, ad.ldv = q_src.shape[2], k_src.shape[2], v_src.shape[2]
+    ad.sq, ad.sk, ad.sv = Lq * q_src.shape[2], Lk * k_src.shape[2], Lk * v_src.shape[2]
+    ad.ldo, ad.so = heads * d, Lq * heads * d
+    ad.causal, ad.scale = int(causal), alpha
+    ad.drop_p, ad.seed, ad.offset = drop if drop is not None else (0.0, 0, 0)
+    return ad
+
+
 class AttentionFn(Function):
     @staticmethod
     def forward(ctx, q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid, causal, p_drop):
         """*_src: [N, L, W] contiguous tensors holding the projections at column offset *_off (width heads*d);
-        the same tensor may be passed for several roles (packed QKV).  key_valid uint8 [N, Lk] or None."""
+        the same tensor may be passed for several roles (packed QKV).  key_valid uint8 [N, Lk] or None.
+        bf16 with a built head size runs the fused kernel (no score tensor); otherwise GEMM + softmax + GEMM."""
         N, Lq, _ = q_src.shape
         Lk = k_src.shape[1]
         dt, dev = q_src.dtype, q_src.device
         E = heads * d
         alpha = 1.0 / math.sqrt(d)
-        S = torch.empty(N, heads, Lq, Lk, dtype=dt, device=dev)
-        gemm(q_src, k_src, S, Lq, Lk, d, q_src.shape[2], k_src.shape[2], Lk, a_off=q_off, b_off=k_off, batch1=N, batch2=heads,
-             sa=(Lq * q_src.shape[2], d), sb=(Lk * k_src.shape[2], d), sc=(heads * Lq * Lk, Lq * Lk), alpha=alpha)
-        drop, Pd = None, S
-        if p_drop > 0.0:
-            drop = (p_drop,) + config.next_rng(S.numel())
-            Pd = torch.empty_like(S)
-        sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
-        A.call("case_softmax_fwd", sd, _ptr(S), _ptr(key_valid), None, _ptr(S), _ptr(Pd), _stream())  # in place: S -> P
+        drop = (p_drop,) + config.next_rng(N * heads * Lq * Lk) if p_drop > 0.0 else None
         O = torch.empty(N, Lq, E, dtype=dt, device=dev)
-        gemm(Pd, v_src, O, Lq, d, Lk, Lk, v_src.shape[2], E, b_off=v_off, b_kmajor=True, batch1=N, batch2=heads,
-             sa=(heads * Lq * Lk, Lq * Lk), sb=(Lk * v_src.shape[2], d), sc=(Lq * E, d))
-        ctx.save_for_backward(q_src, k_src, v_src, S, Pd if drop is not None else None)
-        ctx.meta = (q_off, k_off, v_off, heads, d, causal, drop, alpha)
+        fused = _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d)
+        if fused:
+            lse = torch.empty(N, heads, Lq, dtype=torch.float32, device=dev)
+            ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)
+            A.call("case_attention_fwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O),
+                   _ptr(lse), _stream())
+            ctx.save_for_backward(q_src, k_src, v_src, key_valid, O, lse)
+        else:
+            S, Pd = AttentionFn._probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha)
+            gemm(Pd, v_src, O, Lq, d, Lk, Lk, v_src.shape[2], E, b_off=v_off, b_kmajor=True, batch1=N, batch2=heads,
+                 sa=(heads * Lq * Lk, Lq * Lk), sb=(Lk * v_src.shape[2], d), sc=(Lq * E, d))
+            ctx.save_for_backward(q_src, k_src, v_src, key_valid, S, Pd if drop is not None else None)
+        ctx.meta = (q_off, k_off, v_off, heads, d, causal, drop, alpha, fused)
         return O
 
     @staticmethod
+    def _grad_buffers(q_src, k_src, v_src, E):
+        """One gradient buffer per distinct source tensor (packed projections share one)."""
+        bufs = {}
+        for src in (q_src, k_src, v_src):
+            key = src.data_ptr()
+            if key not in bufs:
+                covered = sum(E for t in (q_src, k_src, v_src) if t.data_ptr() == key)
+                bufs[key] = torch.empty_like(src) if covered == src.shape[2] else torch.zeros_like(src)
+        return bufs
+
+    @staticmethod
+    def _fused_backward(ctx, dO):
+        q_src, k_src, v_src, key_valid, O, lse = ctx.saved_tensors
+        q_off, k_off, v_off, heads, d, causal, drop, alpha, _ = ctx.meta
+        N, Lq, _ = q_src.shape
+        Lk = k_src.shape[1]
+        dO = dO if dO.is_contiguous() else dO.contiguous()
+        bufs = AttentionFn._grad_buffers(q_src, k_src, v_src, heads * d)
+        gq, gk, gv = bufs[q_src.data_ptr()], bufs[k_src.data_ptr()], bufs[v_src.data_ptr()]
+        delta = torch.empty(N, heads, Lq, dtype=torch.float32, device=dO.device)
+        ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)
+        A.call("case_attention_bwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O), _ptr(lse),
+               _ptr(dO), _ptr(delta), _ptr(gq, q_off), _ptr(gk, k_off), _ptr(gv, v_off), _stream())
+        out, seen = [], set()
+        for src in (q_src, k_src, v_src):
+            key = src.data_ptr()
+            out.append(None if key in seen else bufs[key])
+            seen.add(key)
+        return (out[0], out[1], out[2]) + (None,) * 8
+
+    @staticmethod
+    def _probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha):
+        """P = softmax(alpha Q K^T | masks) [N, h, Lq, Lk] and its dropped-out copy (same tensor when drop is None)."""
+        N, Lq, _ = q_src.shape
+        Lk = k_src.shape[1]
+        dt = q_src.dtype
+        S = torch.empty(N, heads, Lq, Lk, dtype=dt, device=q_src.device)
+        gemm(q_src, k_src, S, Lq, Lk, d, q_src.shape[2], k_src.shape[2], Lk, a_off=q_off, b_off=k_off, batch1=N, batch2=heads,
+             sa=(Lq * q_src.shape[2], d), sb=(Lk * k_src.shape[2], d), sc=(heads * Lq * Lk, Lq * Lk), alpha=alpha)
+        Pd = torch.empty_like(S) if drop is not None else S
+        sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
+        A.call("case_softmax_fwd", sd, _ptr(S), _ptr(key_valid), None, _ptr(S), _ptr(Pd), _stream())  # in place: S -> P
+        return S, Pd
+
+    @staticmethod
     def backward(ctx, dO):
-        q_src, k_src, v_src, P, Pd = ctx.saved_tensors
-        q_off, k_off, v_off, heads, d, causal, drop, alpha = ctx.meta
-        if Pd is None:
-            Pd = P
+        q_off, k_off, v_off, heads, d, causal, drop, alpha, fused = ctx.meta
+        if fused and A.lib.case_attention_bwd_supported(d):
+            return AttentionFn._fused_backward(ctx, dO)
+        if fused:
+            q_src, k_src, v_src, key_valid, _, _ = ctx.saved_tensors
+            P, Pd = AttentionFn._probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha)
+        else:
+            q_src, k_src, v_src, key_valid, P, Pd = ctx.saved_tensors
+            if Pd is None:
+                Pd = P
         N, Lq, Wq = q_src.shape
         Lk, Wk, Wv = k_src.shape[1], k_src.shape[2], v_src.shape[2]
         E = heads * d
@@ -391,7 +464,7 @@ class AttentionFn(Function):
         def grad_of(src):
             key = src.data_ptr()
             if key not in bufs:
-                covered = sum(E for s, _ in ((q_src, 0), (k_src, 0), (v_src, 0)) if s.data_ptr() == key)
+                covered = sum(E for s in (q_src, k_src, v_src) if s.data_ptr() == key)
                 bufs[key] = (torch.empty_like(src) if covered == src.shape[2] else torch.zeros_like(src))
             return bufs[key]
 

@@ -139,6 +139,37 @@ int case_softmax_fwd(const CaseSoftmaxDesc* d, const void* x, const uint8_t* col
 int case_softmax_bwd(const CaseSoftmaxDesc* d, const void* dy, const void* p, void* dx, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K4 / K5 / K6  fused multi-head attention (bf16): softmax(scale * Q K^T + masks) V without materialising the scores
+ *   nn.MultiheadAttention call sites: common/TransformerEncoder.py:67, common/TransformerBlock.py:26 (self-attention
+ *   with key padding, head_dim 64 and 5H/8 = 320), common/TransformerDecoder.py:77 (causal + key padding), :81 (cross
+ *   attention over the S = P*Lp token memory).
+ * q / k / v point at the first head's columns inside the (packed) projection tensors: element (n, l, head, j) is at
+ * base[n*s? + l*ld? + head*head_dim + j].  key_valid u8 [N, Lk] (1 = token) or null; causal masks key > query.
+ * out bf16 [N, Lq, heads*head_dim] (row stride ldo, sequence stride so); lse f32 [N, heads, Lq] is saved for backward.
+ * Dropout acts on the probabilities with the same counter RNG / element index as case_softmax_fwd on [N, heads, Lq, Lk].
+ * Backward: delta f32 [N, heads, Lq] is scratch (rowsum(dO * O), written by the call); dq / dk / dv are bf16 slices of
+ * the gradient of the packed projections, addressed with the same strides as q / k / v.
+ * case_attention_supported(head_dim) != 0 tells whether a head size is built (forward: 64, 320; backward: 64 -- see
+ * case_attention_bwd_supported); other sizes use the unfused GEMM + softmax path.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t N, heads, Lq, Lk, head_dim;
+  int64_t ldq, ldk, ldv, sq, sk, sv;
+  int64_t ldo, so;
+  int32_t causal;
+  float scale, drop_p;
+  uint64_t seed, offset;
+} CaseAttnDesc;
+
+int case_attention_supported(int64_t head_dim);
+int case_attention_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                       void* out, float* lse, case_stream_t stream);
+int case_attention_bwd_supported(int64_t head_dim);
+int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                       const void* out, const float* lse, const void* dout, float* delta, void* dq, void* dk, void* dv,
+                       case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * elementwise / small reductions
  * ------------------------------------------------------------------------------------------- */
 /* out = a + b  (residual adds: TransformerEncoder.py:68,75 etc.) */

@@ -253,3 +253,87 @@ def test_gemm_rejects_bad_arguments():
         ops.gemm(a, a, a, 0, 4, 4, 4, 4, 4)
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.linear(torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+@pytest.mark.parametrize("N,h,Lq,Lk,d,causal", [(2, 8, 384, 384, 64, False), (2, 8, 384, 384, 320, False), (3, 8, 40, 40, 64, True),
+                                                 (2, 8, 40, 520, 64, False), (2, 2, 200, 333, 320, False)])
+def test_fused_attention_matches_unfused_and_reference(N, h, Lq, Lk, d, causal):
+    """bf16 fused kernel (no score tensor) vs the f32 reference and vs the unfused GEMM+softmax path, incl. identical
+    dropout masks (same counter RNG / element index)."""
+    from case_rg_amd import _abi, config
+    ops = _ops()
+    assert _abi.lib.case_attention_supported(d)
+    E, dt = h * d, torch.bfloat16
+    valid = torch.ones(N, Lk, dtype=torch.bool, device=DEV)
+    valid[1, Lk // 2 + 3:] = False
+    self_attn = Lq == Lk
+    if self_attn:
+        src = _rand(N, Lq, 3 * E, dt=dt, seed=1, scale=0.7).requires_grad_()
+        args = (src, src, src, 0, E, 2 * E)
+        q, k, v = src.detach().float().split(E, dim=-1)
+    else:
+        qs = _rand(N, Lq, E, dt=dt, seed=1, scale=0.7).requires_grad_()
+        kv = _rand(N, Lk, 2 * E, dt=dt, seed=2, scale=0.7).requires_grad_()
+        args = (qs, kv, kv, 0, 0, E)
+        q, (k, v) = qs.detach().float(), kv.detach().float().split(E, dim=-1)
+    o = ops.attention(*args, h, d, key_valid=valid, causal=causal)
+    qh, kh, vh = [t.reshape(N, -1, h, d).transpose(1, 2) for t in (q, k, v)]
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    if causal:
+        s = s + torch.triu(torch.full((Lq, Lk), float("-inf"), device=DEV), 1)
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(N, Lq, E)
+    _close(o, ref, 2e-2, "fused attn o")
+    g = _rand(N, Lq, E, dt=dt, seed=3)
+    o.backward(g)
+    # gradients against the f32 reference of the same (bf16-rounded) inputs
+    leaves = [t for t in (args[0], args[1]) if t.requires_grad]
+    leaves = [leaves[0]] if self_attn else leaves
+    refs = [t.detach().float().requires_grad_() for t in leaves]
+    if self_attn:
+        rq, rk, rv = refs[0].split(E, dim=-1)
+    else:
+        rq, (rk, rv) = refs[0], refs[1].split(E, dim=-1)
+    rqh, rkh, rvh = [t.reshape(N, -1, h, d).transpose(1, 2) for t in (rq, rk, rv)]
+    rs = (rqh @ rkh.transpose(-1, -2)) / math.sqrt(d)
+    rs = rs.masked_fill(~valid[:, None, None, :], float("-inf"))
+    if causal:
+        rs = rs + torch.triu(torch.full((Lq, Lk), float("-inf"), device=DEV), 1)
+    (torch.softmax(rs, -1) @ rvh).transpose(1, 2).reshape(N, Lq, E).backward(g.float())
+    for a_, r_ in zip(leaves, refs):
+        _close(a_.grad, r_.grad, 4e-2, "fused attn grad")
+    # dropout: fused forward must equal the unfused path bit-for-bit in its mask (compare through the outputs)
+    config.set_dropout(True)
+    try:
+        config.manual_seed(11)
+        o_f = ops.attention(*[a.detach() if torch.is_tensor(a) else a for a in args], h, d, key_valid=valid, causal=causal, p_drop=0.1)
+        config.manual_seed(11)
+        saved = _abi.lib.case_attention_supported
+        try:
+            _abi.lib.case_attention_supported = lambda _d: 0
+            o_u = ops.attention(*[a.detach() if torch.is_tensor(a) else a for a in args], h, d, key_valid=valid, causal=causal, p_drop=0.1)
+        finally:
+            _abi.lib.case_attention_supported = saved
+        _close(o_f, o_u, 2e-2, "fused vs unfused with dropout")
+        # and the fused backward (where built) regenerates that same mask: gradients agree with the unfused path
+        if _abi.lib.case_attention_bwd_supported(d):
+            grads = []
+            for fused_on in (True, False):
+                config.manual_seed(11)
+                ins = [a.detach().clone().requires_grad_() if torch.is_tensor(a) else a for a in args]
+                if self_attn:
+                    ins[1] = ins[2] = ins[0]
+                else:
+                    ins[2] = ins[1]
+                saved = _abi.lib.case_attention_supported
+                try:
+                    if not fused_on:
+                        _abi.lib.case_attention_supported = lambda _d: 0
+                    ops.attention(*ins, h, d, key_valid=valid, causal=causal, p_drop=0.1).backward(g)
+                finally:
+                    _abi.lib.case_attention_supported = saved
+                grads.append([t.grad for t in (ins[0], ins[1]) if t.grad is not None])
+            for gf, gu in zip(*grads):
+                _close(gf, gu, 4e-2, "fused vs unfused gradients with dropout")
+    finally:
+        config.set_dropout(False)
