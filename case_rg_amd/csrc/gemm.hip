@@ -94,7 +94,7 @@ __device__ __forceinline__ unsigned stage_load(u32x4 (&regs)[4], const T* __rest
   return okmask;
 }
 
-template <typename T, bool KMAJOR>
+template <typename T, bool KMAJOR, bool FULL = false>
 __device__ __forceinline__ void stage_store(const u32x4 (&regs)[4], unsigned okmask, char* lds) {
   const int tid = threadIdx.x;
   const u32x4 z = {0u, 0u, 0u, 0u};
@@ -108,9 +108,96 @@ __device__ __forceinline__ void stage_store(const u32x4 (&regs)[4], unsigned okm
       constexpr int CPR = BM * sizeof(T) / 16;
       off = (c / CPR) * KM<T>::row_stride + (c % CPR) * 16;
     }
-    *reinterpret_cast<u32x4*>(lds + off) = ((okmask >> i) & 1u) ? regs[i] : z;
+    if constexpr (FULL) *reinterpret_cast<u32x4*>(lds + off) = regs[i];
+    else *reinterpret_cast<u32x4*>(lds + off) = ((okmask >> i) & 1u) ? regs[i] : z;
   }
 }
+
+// Loads that hipcc does not count: the FULL-tile K loop keeps two tiles of global loads in flight across iterations and
+// needs counted waits (s_waitcnt vmcnt(8): "all but the 8 youngest"), but hipcc's own bookkeeping drains to vmcnt(0)
+// before the first LDS write of the older tile (it cannot see that the younger tile's loads are not needed yet), which
+// turns the distance-2 prefetch back into distance 1.  So the loads are issued from inline asm (SGPR base + 32-bit VGPR
+// offset form) and retired by wait_tile<N>(), which names every destination register so no consumer can be scheduled
+// above it.
+__device__ __forceinline__ void gload16_async(u32x4& dst, unsigned voff, const char* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_tile(u32x4 (&a)[4], u32x4 (&b)[4]) {
+  if constexpr (N == 8)
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+}
+
+// Tile loader for the vector path.  Per-thread state is one 32-bit byte offset per 16-byte chunk, fixed for the whole K
+// loop; the tile advances through a wave-uniform base pointer (scalar add), so the loads use the SGPR-base + VGPR-offset
+// form and the main loop carries no per-chunk address arithmetic.  FULL tiles (no M / N / K edge) skip every bounds
+// select: the generic path costs ~9 VALU instructions per MFMA, which competes with MFMA issue at two waves per SIMD.
+template <typename T, bool KMAJOR>
+struct Loader {
+  const char* base;   // uniform: first element of the current tile (compiler-visible global pointer, edge-tile path)
+  const char* sbase;  // the same address forced into SGPRs for the inline-asm loads of the FULL path
+  unsigned off[4];
+  int kofs[4];
+  unsigned mnok;
+  int64_t step;
+  __device__ __forceinline__ void init(const T* __restrict__ op, int64_t ld, int64_t mn0, int64_t mn_max, int64_t k0) {
+    constexpr int EPT = 16 / sizeof(T);
+    constexpr int BKE = ROWB / sizeof(T);
+    const int tid = threadIdx.x;
+    mnok = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * NTHREADS;
+      if constexpr (!KMAJOR) {
+        const int row = c >> 3, kc = c & 7;
+        const bool ok = mn0 + row < mn_max;
+        off[i] = ok ? (unsigned)((row * ld + kc * EPT) * (int64_t)sizeof(T)) : 0u;
+        kofs[i] = kc * EPT;
+        mnok |= (ok ? 1u : 0u) << i;
+      } else {
+        constexpr int CPR = BM * sizeof(T) / 16;
+        const int krow = c / CPR, nc = c % CPR;
+        const bool ok = mn0 + nc * EPT < mn_max;
+        off[i] = ok ? (unsigned)((krow * ld + nc * EPT) * (int64_t)sizeof(T)) : 0u;
+        kofs[i] = krow;
+        mnok |= (ok ? 1u : 0u) << i;
+      }
+    }
+    base = reinterpret_cast<const char*>(KMAJOR ? op + k0 * ld + mn0 : op + mn0 * ld + k0);
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    // wave-uniform by construction (kernel arguments and blockIdx only); readfirstlane makes that provable so the
+    // pointer stays in SGPRs for the saddr load form
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));  // builtin returns int: go through
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffull));  // unsigned before widening
+    sbase = reinterpret_cast<const char*>(((uint64_t)hi << 32) | (uint64_t)lo);
+    // hazard: an SGPR written by v_readfirstlane (VALU) needs 5 wait states before a VMEM instruction may read it as its
+    // scalar base; hipcc pads this for its own instructions only, not for the inline-asm loads that consume `sbase`
+    asm volatile("s_nop 4" : "+s"(sbase));
+    step = (KMAJOR ? (int64_t)BKE * ld : (int64_t)BKE) * (int64_t)sizeof(T);
+  }
+  // loads the tile whose first k index is k0 and advances to the next tile
+  template <bool FULL>
+  __device__ __forceinline__ unsigned load(u32x4 (&regs)[4], int64_t k0, int64_t k_max) {
+    unsigned okmask = 0xFu;
+    if constexpr (FULL) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gload16_async(regs[i], off[i], sbase);
+      sbase += step;
+    } else {
+      okmask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = ((mnok >> i) & 1u) && (k0 + kofs[i] < k_max);
+        regs[i] = *reinterpret_cast<const u32x4*>(base + (ok ? off[i] : 0u));
+        okmask |= (ok ? 1u : 0u) << i;
+      }
+    }
+    base += step;
+    return okmask;
+  }
+};
 
 // ---- LDS -> MFMA fragments ------------------------------------------------------------------
 // bf16, k-step ks in [0,4): lane (r = l&31, h = l>>5) needs k = 16 ks + 8 h + j, j = 0..7, of row/col (32 t + r).
@@ -190,6 +277,78 @@ __device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const char* la, co
   }
 }
 
+// Software-pipelined K loop.  Two register sets: while tile kt is multiplied out of LDS, tile kt+1 (set X) has already
+// been requested one iteration ago and tile kt+2 (set Y) is requested now, so every global load has two MFMA phases
+// (x 2 co-resident workgroups) to land before its s_waitcnt -- one phase does not cover HBM / Infinity-Cache latency
+// under load.  LDS is double-buffered: one barrier per K tile.
+template <typename T, bool AK, bool BK_, bool VEC, bool FULL>
+__device__ __forceinline__ void k_loop(f32x16 (&acc)[2][2], char* smem, const T* __restrict__ A, const T* __restrict__ B,
+                                       const Args& g, int64_t m0, int64_t n0, int kt_begin, int kt_end, int wr, int wc) {
+  constexpr int BKE = ROWB / sizeof(T);
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+  unsigned oka0, okb0, oka1 = 0, okb1 = 0;
+  Loader<T, AK> lda_;
+  Loader<T, BK_> ldb_;
+  if constexpr (VEC) {
+    lda_.init(A, g.lda, m0, g.M, (int64_t)kt_begin * BKE);
+    ldb_.init(B, g.ldb, n0, g.N, (int64_t)kt_begin * BKE);
+  }
+#define LOAD_A(R, KT) (VEC ? lda_.template load<FULL>(R, (int64_t)(KT) * BKE, g.K) : stage_load<T, AK, false>(R, A, g.lda, m0, g.M, (int64_t)(KT) * BKE, g.K))
+#define LOAD_B(R, KT) (VEC ? ldb_.template load<FULL>(R, (int64_t)(KT) * BKE, g.K) : stage_load<T, BK_, false>(R, B, g.ldb, n0, g.N, (int64_t)(KT) * BKE, g.K))
+  oka0 = LOAD_A(ra0, kt_begin);
+  okb0 = LOAD_B(rb0, kt_begin);
+  if constexpr (FULL) wait_tile<0>(ra0, rb0);
+  stage_store<T, AK, FULL>(ra0, oka0, smem);
+  stage_store<T, BK_, FULL>(rb0, okb0, smem + OP_BYTES);
+  if (kt_begin + 1 < kt_end) {
+    oka0 = LOAD_A(ra0, kt_begin + 1);
+    okb0 = LOAD_B(rb0, kt_begin + 1);
+  }
+  __syncthreads();
+  int cur = 0;
+  // one K tile: [request tile KT+2 into the FAR set] -> multiply tile KT out of LDS -> [retire the NEXT set (tile KT+1)
+  // and write it to the other LDS buffer] -> barrier.  FARC / NEXTC say (uniformly) whether those tiles exist; WAITN is
+  // the counted wait of the FULL path (8 = the FAR tile's eight loads may stay in flight).
+#define GEMM_STEP(KT, FARC, NEXTC, WAITN, RA_NEXT, RB_NEXT, OKA_NEXT, OKB_NEXT, RA_FAR, RB_FAR, OKA_FAR, OKB_FAR)  \
+  {                                                                                                                \
+    if (FARC) {                                                                                                    \
+      OKA_FAR = LOAD_A(RA_FAR, (KT) + 2);                                                                          \
+      OKB_FAR = LOAD_B(RB_FAR, (KT) + 2);                                                                          \
+    }                                                                                                              \
+    const char* la = smem + cur * STAGE_BYTES;                                                                     \
+    mma_tile<T, AK, BK_>(acc, la, la + OP_BYTES, wr, wc);                                                          \
+    if (NEXTC) {                                                                                                   \
+      char* nx = smem + (cur ^ 1) * STAGE_BYTES;                                                                   \
+      if constexpr (FULL) wait_tile<WAITN>(RA_NEXT, RB_NEXT);                                                      \
+      stage_store<T, AK, FULL>(RA_NEXT, OKA_NEXT, nx);                                                             \
+      stage_store<T, BK_, FULL>(RB_NEXT, OKB_NEXT, nx + OP_BYTES);                                                 \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+    cur ^= 1;                                                                                                      \
+  }
+  int kt = kt_begin;
+  // steady state: both the NEXT and the FAR tile exist for the two unrolled steps
+  for (; kt + 3 < kt_end; kt += 2) {
+    GEMM_STEP(kt, true, true, 8, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1)
+    GEMM_STEP(kt + 1, true, true, 8, ra1, rb1, oka1, okb1, ra0, rb0, oka0, okb0)
+  }
+  // tail: 1..3 tiles left; set 0 holds tile kt+1 (if any)
+  const int left = kt_end - kt;
+  if (left == 3) {
+    GEMM_STEP(kt, true, true, 8, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1)
+    GEMM_STEP(kt + 1, false, true, 0, ra1, rb1, oka1, okb1, ra0, rb0, oka0, okb0)
+    GEMM_STEP(kt + 2, false, false, 0, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1)
+  } else if (left == 2) {
+    GEMM_STEP(kt, false, true, 0, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1)
+    GEMM_STEP(kt + 1, false, false, 0, ra1, rb1, oka1, okb1, ra0, rb0, oka0, okb0)
+  } else if (left == 1) {
+    GEMM_STEP(kt, false, false, 0, ra0, rb0, oka0, okb0, ra1, rb1, oka1, okb1)
+  }
+#undef GEMM_STEP
+#undef LOAD_A
+#undef LOAD_B
+}
+
 // Per-element epilogue; order: alpha*acc + bias -> GELU|RELU -> MUL_D* -> DROPOUT -> + RESIDUAL -> store.
 template <typename T, typename OutT>
 struct Epilogue {
@@ -239,10 +398,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g, const i
     const int nwg = g.nwg, q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = pid % g.tiles_n;
-  int rest = pid / g.tiles_n;
-  const int tm = rest % g.tiles_m;
-  rest /= g.tiles_m;
+  // grouped rasterisation inside one (batch, split) slab: GM row-tiles share their column tiles, so the ~64 workgroups
+  // co-resident on an XCD touch ~8 A panels + ~8 B panels (K slices of both stay hot in the 4 MiB L2) instead of one A
+  // panel and every B panel
+  const int per_slab = g.tiles_m * g.tiles_n;
+  const int in_slab = pid % per_slab;
+  int rest = pid / per_slab;
+  constexpr int GM = 8;
+  const int group = in_slab / (GM * g.tiles_n);
+  const int first_m = group * GM;
+  const int gm = min(GM, g.tiles_m - first_m);
+  const int tm = first_m + (in_slab - group * GM * g.tiles_n) % gm;
+  const int tn = (in_slab - group * GM * g.tiles_n) / gm;
   const int split = rest % g.split_k;
   const int64_t batch = rest / g.split_k;
   const int64_t b1 = batch / g.batch2, b2 = batch % g.batch2;
@@ -265,29 +432,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g, const i
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (kt_begin < kt_end) {
-    u32x4 ra[4], rb[4];
-    unsigned oka = stage_load<T, AK, VEC>(ra, A, g.lda, m0, g.M, (int64_t)kt_begin * BKE, g.K);
-    unsigned okb = stage_load<T, BK_, VEC>(rb, B, g.ldb, n0, g.N, (int64_t)kt_begin * BKE, g.K);
-    stage_store<T, AK>(ra, oka, smem);
-    stage_store<T, BK_>(rb, okb, smem + OP_BYTES);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = kt + 1 < kt_end;
-      if (more) {
-        oka = stage_load<T, AK, VEC>(ra, A, g.lda, m0, g.M, (int64_t)(kt + 1) * BKE, g.K);
-        okb = stage_load<T, BK_, VEC>(rb, B, g.ldb, n0, g.N, (int64_t)(kt + 1) * BKE, g.K);
-      }
-      const char* la = smem + cur * STAGE_BYTES;
-      mma_tile<T, AK, BK_>(acc, la, la + OP_BYTES, wr, wc);
-      if (more) {
-        char* nx = smem + (cur ^ 1) * STAGE_BYTES;
-        stage_store<T, AK>(ra, oka, nx);
-        stage_store<T, BK_>(rb, okb, nx + OP_BYTES);
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
+    const bool full = VEC && (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.K % BKE == 0) &&
+                      (uint64_t)g.lda * (uint64_t)(AK ? BKE : BM) * sizeof(T) < (1ull << 32) &&
+                      (uint64_t)g.ldb * (uint64_t)(BK_ ? BKE : BN) * sizeof(T) < (1ull << 32);
+    if (full) k_loop<T, AK, BK_, VEC, true>(acc, smem, A, B, g, m0, n0, kt_begin, kt_end, wr, wc);
+    else k_loop<T, AK, BK_, VEC, false>(acc, smem, A, B, g, m0, n0, kt_begin, kt_end, wr, wc);
   }
 
   // ---- epilogue: acc[i][j][reg] is C[row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)][col = lane & 31] ------

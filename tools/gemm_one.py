@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""One GEMM shape, a few launches: target for rocprofv3 --pmc runs."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from case_rg_amd import ops  # noqa: E402
+
+M, K, N = [int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (122880, 2560, 7680))]
+mode = sys.argv[4] if len(sys.argv) > 4 else "nt"
+x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+for _ in range(3):
+    if mode == "nt":
+        ops.gemm(x, w, y, M, N, K, K, K, N)
+    else:
+        g = y
+        ops.gemm(g, w, x, M, K, N, N, K, K, b_kmajor=True)
+torch.cuda.synchronize()
