@@ -47,6 +47,7 @@ struct Args {
   float alpha, drop_p;
   uint64_t seed, offset;
   int vec_a, vec_b;  // 16-byte global loads are legal for the operand
+  int vec_c;         // 16-byte accesses are legal for C / aux / aux_out / bias_col
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -349,10 +350,20 @@ __device__ __forceinline__ void k_loop(f32x16 (&acc)[2][2], char* smem, const T*
 #undef LOAD_B
 }
 
+constexpr int CT_STRIDE = 132;  // floats per row of the staged C tile (528 B: 16-byte aligned, rows shifted by 4 banks)
+static_assert(BM * CT_STRIDE * 4 <= 2 * STAGE_BYTES, "staged C tile must fit in the K-loop buffers");
+
+// accumulator tile -> staged C tile: register e is row (e&3) + 8 (e>>2) (+ 4 per lane half, folded into r0), lane = column
+__device__ __forceinline__ void stage_acc(float* ctile, const f32x16& a, int r0, int c0) {
+  float* base = ctile + r0 * CT_STRIDE + c0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) base[((e & 3) + 8 * (e >> 2)) * CT_STRIDE] = a[e];
+}
+
 // Per-element epilogue; order: alpha*acc + bias -> GELU|RELU -> MUL_D* -> DROPOUT -> + RESIDUAL -> store.
 template <typename T, typename OutT>
 struct Epilogue {
-  OutT* C; const T* aux; T* aux_out; const float* bias_row;
+  OutT* C; const T* aux; T* aux_out; const float* bias_row; const float* bias_col;
   int64_t ldc, ld_aux, M, N;
   float alpha, drop_p, drop_scale;
   uint64_t seed, rng_base;
@@ -378,12 +389,82 @@ struct Epilogue {
       Elem<OutT>::st(dst, v);
     }
   }
-  __device__ __forceinline__ void tile(const f32x16& a, int64_t row0, int64_t col, const float* bias_col) const {
+  __device__ __forceinline__ void tile(const f32x16& a, int64_t row0, int64_t col) const {
     const float bc = ((epi & CASE_EPI_BIAS_COL) && col < N) ? bias_col[col] : 0.f;
     emit(a[0], row0 + 0, col, bc);   emit(a[1], row0 + 1, col, bc);   emit(a[2], row0 + 2, col, bc);   emit(a[3], row0 + 3, col, bc);
     emit(a[4], row0 + 8, col, bc);   emit(a[5], row0 + 9, col, bc);   emit(a[6], row0 + 10, col, bc);  emit(a[7], row0 + 11, col, bc);
     emit(a[8], row0 + 16, col, bc);  emit(a[9], row0 + 17, col, bc);  emit(a[10], row0 + 18, col, bc); emit(a[11], row0 + 19, col, bc);
     emit(a[12], row0 + 24, col, bc); emit(a[13], row0 + 25, col, bc); emit(a[14], row0 + 26, col, bc); emit(a[15], row0 + 27, col, bc);
+  }
+  // second phase of the LDS-staged epilogue: each thread owns 8 chunks of 8 consecutive columns of one row
+  __device__ __forceinline__ void store_tile(const float* ctile, int64_t m0, int64_t n0, bool vec) const {
+    constexpr int EO = 16 / sizeof(OutT) > 8 ? 8 : 8;  // 8 columns per chunk for every dtype
+    (void)EO;
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+      const int c = threadIdx.x + i * NTHREADS;
+      const int r = c >> 4, cc = (c & 15) * 8;
+      const int64_t row = m0 + r, col = n0 + cc;
+      if (row >= M || col >= N) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * CT_STRIDE + cc);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * CT_STRIDE + cc + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const bool full = vec && col + 8 <= N;
+      if (full) {
+        // ---- vector path: bias / aux as 16-byte (bf16) or 2 x 16-byte (f32) loads, C as one or two 16-byte stores
+        float ax[8];
+        const bool need_aux = epi & (CASE_EPI_RESIDUAL | CASE_EPI_MUL_DGELU | CASE_EPI_MUL_DRELU);
+        if (need_aux) load8(aux + row * ld_aux + col, ax);
+        float bc[8];
+        if (epi & CASE_EPI_BIAS_COL) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_col + col), b1 = *reinterpret_cast<const f32x4*>(bias_col + col + 4);
+          bc[0] = b0[0]; bc[1] = b0[1]; bc[2] = b0[2]; bc[3] = b0[3]; bc[4] = b1[0]; bc[5] = b1[1]; bc[6] = b1[2]; bc[7] = b1[3];
+        }
+        const float br = (epi & CASE_EPI_BIAS_ROW) ? bias_row[row] : 0.f;
+        float z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = alpha * v[e] + ((epi & CASE_EPI_BIAS_COL) ? bc[e] : 0.f) + br;
+          z[e] = x;
+          if (epi & CASE_EPI_GELU) x = gelu_f(x);
+          if (epi & CASE_EPI_RELU) x = fmaxf(x, 0.f);
+          if (epi & CASE_EPI_MUL_DGELU) x *= dgelu_f(ax[e]);
+          if (epi & CASE_EPI_MUL_DRELU) x = ax[e] > 0.f ? x : 0.f;
+          if (epi & CASE_EPI_DROPOUT) x = rng_uniform(seed, rng_base + (uint64_t)(row * N + col + e)) >= drop_p ? x * drop_scale : 0.f;
+          if (epi & CASE_EPI_RESIDUAL) x += ax[e];
+          v[e] = x;
+        }
+        if ((epi & CASE_EPI_GELU) && aux_out) store8(aux_out + row * ld_aux + col, z);
+        store8(C + row * ldc + col, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          emit(v[e], row, col + e, ((epi & CASE_EPI_BIAS_COL) && col + e < N) ? bias_col[col + e] : 0.f);
+      }
+    }
+  }
+  static __device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  }
+  static __device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+  static __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = w;
   }
 };
 
@@ -439,23 +520,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g, const i
     else k_loop<T, AK, BK_, VEC, false>(acc, smem, A, B, g, m0, n0, kt_begin, kt_end, wr, wc);
   }
 
-  // ---- epilogue: acc[i][j][reg] is C[row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)][col = lane & 31] ------
+  // ---- epilogue -----------------------------------------------------------------------------------------------------
   const int lane = threadIdx.x & 63;
   Epilogue<T, OutT> ep;
   ep.C = reinterpret_cast<OutT*>(g.C) + b1 * g.sc1 + b2 * g.sc2;
   ep.aux = g.aux ? reinterpret_cast<const T*>(g.aux) + b1 * g.saux1 + b2 * g.saux2 : nullptr;
   ep.aux_out = g.aux_out ? reinterpret_cast<T*>(g.aux_out) + b1 * g.saux1 + b2 * g.saux2 : nullptr;
   ep.bias_row = g.bias_row ? g.bias_row + batch * g.M : nullptr;
+  ep.bias_col = g.bias_col;
   ep.ldc = g.ldc; ep.ld_aux = g.ld_aux; ep.M = g.M; ep.N = g.N;
   ep.alpha = g.alpha; ep.drop_p = g.drop_p; ep.seed = g.seed;
   ep.rng_base = g.offset + (uint64_t)(batch * g.M * g.N);
   ep.drop_scale = (epi & CASE_EPI_DROPOUT) ? 1.f / (1.f - g.drop_p) : 1.f;
   ep.epi = (split == 0) ? epi : (epi & ~(CASE_EPI_BIAS_COL | CASE_EPI_BIAS_ROW));
-  const int64_t col_base = n0 + wc * 64 + (lane & 31), row_base = m0 + wr * 64 + 4 * (lane >> 5);
-  ep.tile(acc[0][0], row_base, col_base, g.bias_col);
-  ep.tile(acc[0][1], row_base, col_base + 32, g.bias_col);
-  ep.tile(acc[1][0], row_base + 32, col_base, g.bias_col);
-  ep.tile(acc[1][1], row_base + 32, col_base + 32, g.bias_col);
+  if (epi & CASE_EPI_ATOMIC) {
+    // split-K partial sums: f32 atomics straight from the accumulators
+    // (acc[i][j][reg] is C[row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)][col = lane & 31] of its 32x32 tile)
+    const int64_t col_base = n0 + wc * 64 + (lane & 31), row_base = m0 + wr * 64 + 4 * (lane >> 5);
+    ep.tile(acc[0][0], row_base, col_base);
+    ep.tile(acc[0][1], row_base, col_base + 32);
+    ep.tile(acc[1][0], row_base + 32, col_base);
+    ep.tile(acc[1][1], row_base + 32, col_base + 32);
+    return;
+  }
+  // The 128x128 f32 tile goes through LDS (the K loop's buffers are free after its last barrier) so that every global
+  // access of the epilogue -- C, the residual / activation operand, the saved pre-activation -- is a full 16-byte,
+  // row-contiguous vector: the accumulator layout itself offers only 64-byte row segments of 2-byte elements, and 64 such
+  // stores per lane made the short-K GEMMs (K = 512: 8 K tiles) store-issue bound.
+  float* ctile = reinterpret_cast<float*>(smem);
+  {
+    const int c0 = wc * 64 + (lane & 31), r0 = wr * 64 + 4 * (lane >> 5);
+    stage_acc(ctile, acc[0][0], r0, c0);
+    stage_acc(ctile, acc[0][1], r0, c0 + 32);
+    stage_acc(ctile, acc[1][0], r0 + 32, c0);
+    stage_acc(ctile, acc[1][1], r0 + 32, c0 + 32);
+  }
+  __syncthreads();
+  ep.store_tile(ctile, m0, n0, g.vec_c != 0);
 }
 
 template <typename T, typename OutT>
@@ -534,6 +635,14 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
   };
   a.vec_a = aligned(A, d->lda, d->sa1, d->sa2, d->a_kmajor ? d->M : d->K);
   a.vec_b = aligned(B, d->ldb, d->sb1, d->sb2, d->b_kmajor ? d->N : d->K);
+  {
+    const int eo = d->out_dtype == CASE_BF16 ? 8 : 4;  // elements per 16 bytes of C
+    auto ok = [&](const void* p, int64_t ld, int64_t s1, int64_t s2, int e) {
+      return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % e == 0 && s1 % e == 0 && s2 % e == 0);
+    };
+    a.vec_c = ok(C, d->ldc, d->sc1, d->sc2, eo) && ok(aux, d->ld_aux, d->saux1, d->saux2, ept) &&
+              ok(aux_out, d->ld_aux, d->saux1, d->saux2, ept) && ok(bias_col, 4, 0, 0, 4);
+  }
   hipStream_t s = (hipStream_t)stream;
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);

@@ -101,10 +101,22 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
 
 
 def _split_for(out_rows, out_cols, k_len, elem_bytes):
-    """split-K factor for weight-gradient GEMMs: enough workgroups to fill 256 CUs twice."""
+    """split-K factor for weight-gradient GEMMs.  512 workgroups are resident at once (256 CUs x 2); pick the smallest
+    split that (a) gives at least 1024 workgroups and (b) wastes < 8 % of the last round of residency, keeping >= 8 K tiles
+    per split."""
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
     k_tiles = max(1, (k_len * elem_bytes + 127) // 128)
-    return int(max(1, min(k_tiles, (1024 + tiles - 1) // tiles)))
+    best, best_eff = 1, 0.0
+    for split in range(1, 65):
+        if split > 1 and k_tiles // split < 8:
+            break
+        wgs = tiles * split
+        eff = wgs / (((wgs + 511) // 512) * 512.0)
+        if wgs >= 1024 and eff >= 0.92:
+            return split
+        if eff > best_eff + 1e-9:
+            best, best_eff = split, eff
+    return best
 
 
 def _weight_grad(g2, x2, N, K):
