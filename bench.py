@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
+    ap.add_argument("--mode", default="train", choices=["train", "decode"],
+                    help="train: tokens/s of the training step (default, BASELINE cfg 2); decode: greedy answers/s (cfg 4)")
+    ap.add_argument("--decode-len", type=int, default=64)
+    ap.add_argument("--graph", action="store_true", help="decode: replay the whole greedy pass from one captured hipGraph")
     return ap.parse_args()
 
 
@@ -173,6 +177,70 @@ def cpu_baseline(a):
             "sample": "1 training step (fwd+bwd+clip+Adam) of the fp32 CPU oracle at batch 1, same shapes, %.1f s" % dt}
 
 
+def decode_main(a, device, world, rank):
+    """cfg 4: greedy inference, B queries x P passages, T-token answers; a "step" = one whole batch (encode + T cached steps)."""
+    import case_rg_amd
+    from case_rg_amd.common.CumulativeTrainer import init_params
+    from case_rg_amd.common.Utils import init_seed
+    from case_rg_amd.utils import make_vocab, synth_batch
+    case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    init_seed(123456)
+    v2i, i2v = make_vocab(a.vocab)
+    from case_rg_amd.CaSE.Model import CaSE
+    model = CaSE(4, a.decode_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
+    init_params(model)
+    model = model.to(device).eval()
+    batch = synth_batch(a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=123456 + rank, ragged=False)
+    batch = {k: v.to(device) for k, v in batch.items()}
+
+    def run():
+        with torch.no_grad():
+            return model(dict(batch), method="test")
+
+    graph = None
+    for _ in range(max(1, a.warmup)):
+        out = run()
+    if a.graph:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = run()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            out = run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    S, H, T = a.passages * a.passage_len + a.query_len, a.hidden, a.decode_len
+    # algorithmic bytes streamed per item per cached step: 2 stacks x 4 layers x (K+V) of the memory + additive-attention keys
+    bytes_item_step = (4 * 2 * S * H + S * H) * 2
+    res = {
+        "metric": "decode answers/sec (CaSE greedy)", "value": round(world * a.batch * a.steps / elapsed, 2), "unit": "answers/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "CaSE greedy decode (encode + %d KV-cached steps), d_model=%d, %d encoder layers, %d passages x %d tok, "
+                               "per-GPU batch %d%s" % (T, H, a.enc_layers, a.passages, a.passage_len, a.batch, ", hipGraph replay" if a.graph else ""),
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world},
+        "answer_sample": out["answer"][0, :8].tolist(),
+        "decode_stream_gb_per_step": round(bytes_item_step * a.batch / 1e9, 3),
+    }
+    if rank == 0:
+        print(json.dumps(res))
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +252,12 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
+    if a.mode == "decode":
+        decode_main(a, device, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     trainer, opt, sched, batch = build(a, device)
 
     def step():

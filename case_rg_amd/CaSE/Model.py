@@ -37,14 +37,21 @@ class CaSETransformerSeqDecoder(PointerDecoderCore):
                            memory_weights, source_map)
         return (d1, d2) if self.training else d1 + d2
 
-    def _step(self, dec_ids, mems, valid, weights, answer_rep, source_map, cache=None):
-        T = dec_ids.size(1)
+    def _feature(self, answer_rep, T):
+        """LN2(answer_rep) broadcast over the T decoder positions, dropout 0.1 in training (reference :69, :98)."""
         feat = ops.layer_norm(answer_rep, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        feat = ops.dropout(feat.unsqueeze(1).expand(-1, T, -1).contiguous(), 0.1, self.training)
-        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, feat, cache)
+        return ops.dropout(feat.unsqueeze(1).expand(-1, T, -1).contiguous(), 0.1, self.training)
+
+    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
         dec_out = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         gen = self._generate(torch.cat([dec_in, dec_out, feat], dim=-1), self.gen[1].p)
         d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
+        return dec_out, gen, ((d1, d2) if self.training else ops.add(d1, d2))
+
+    def _step(self, dec_ids, mems, valid, weights, answer_rep, source_map, cache=None):
+        feat = self._feature(answer_rep, dec_ids.size(1))
+        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, feat, cache)
+        dec_out, gen, (d1, d2) = self._head(dec_in, x, ctxs, copies, feat, source_map)
         return dec_out, gen, d1, d2
 
     def forward(self, encode_memories, BOS, UNK, source_map, groundtruth_index=None, additional_decoder_feature=None,
@@ -60,14 +67,8 @@ class CaSETransformerSeqDecoder(PointerDecoderCore):
             return dec_out, gen, (d1, d2), groundtruth_index
         if self.training:
             return None
-        cache = self._memory_cache(mems)
-        picked = []
-        for _ in range(max_target_length):
-            dec_ids = torch.cat([bos] + picked, dim=-1)
-            dec_out, gen, d1, d2 = self._step(dec_ids, mems, valid, weights, additional_decoder_feature, source_map, cache)
-            dist = d1 + d2
-            picked.append(ops.row_argmax(dist[:, -1])[0].unsqueeze(1))
-        return dec_out, gen, dist, torch.cat(picked, dim=-1)
+        return self._greedy(mems, valid, weights, source_map, BOS, max_target_length,
+                            feature_of=lambda T: self._feature(additional_decoder_feature, T))
 
 
 class RelevantPassageSelection(nn.Module):

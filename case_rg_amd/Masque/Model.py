@@ -31,12 +31,15 @@ class MasqueTransformerSeqDecoder(PointerDecoderCore):
                            memory_weights, source_map)
         return d1 + d2
 
-    def _step(self, dec_ids, mems, valid, weights, source_map, cache=None):
-        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, None, cache)
+    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
         dec_out = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         gen = self._generate(torch.cat([dec_in, dec_out], dim=-1), 0.0)
         d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
         return dec_out, gen, ops.add(d1, d2)
+
+    def _step(self, dec_ids, mems, valid, weights, source_map, cache=None):
+        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, None, cache)
+        return self._head(dec_in, x, ctxs, copies, None, source_map)
 
     def forward(self, encode_memories, BOS, UNK, source_map, encode_masks=None, encode_weights=None,
                 groundtruth_index=None, init_decoder_state=None, max_target_length=None):
@@ -51,13 +54,7 @@ class MasqueTransformerSeqDecoder(PointerDecoderCore):
             return dec_out, gen, dist, groundtruth_index
         if self.training:
             return None
-        cache = self._memory_cache(mems)
-        picked = []
-        for _ in range(max_target_length):
-            dec_ids = torch.cat([bos] + picked, dim=-1)
-            dec_out, gen, dist = self._step(dec_ids, mems, valid, weights, source_map, cache)
-            picked.append(ops.row_argmax(dist[:, -1])[0].unsqueeze(1))
-        return dec_out, gen, dist, torch.cat(picked, dim=-1)
+        return self._greedy(mems, valid, weights, source_map, BOS, max_target_length)
 
 
 class PassageSelection(nn.Module):

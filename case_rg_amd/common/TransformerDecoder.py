@@ -38,6 +38,24 @@ class TransformerDecoderLayer(nn.Module):
         return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                        self.activation, p_inner=p, p_out=p, residual=x)
 
+    def step(self, x, t, self_kv, hist_valid, memory_kv, memory_valid):
+        """Incremental decoding of position ``t`` (inference): x [N, 1, E]; ``self_kv`` [N, Tmax, 2E] holds the K/V
+        projections of positions < t of THIS layer and receives position t; ``hist_valid`` [N, Tmax] marks the positions
+        <= t whose token is not PAD (the reference's tgt_key_padding_mask, CaSE/Model.py:105).  Equal to re-running the whole
+        prefix (CaSE/Model.py:94-123) because of the causal mask: earlier positions never see later ones."""
+        E = self.self_attn.embed_dim
+        sa, ca = self.self_attn, self.multihead_attn
+        x = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        self_kv[:, t] = qkv[:, 0, E:]
+        ctx = ops.attention(qkv, self_kv, self_kv, 0, 0, E, sa.num_heads, sa.head_dim, key_valid=hist_valid)
+        x = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x)
+        x = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = ca.cross_attention(x, None, memory_valid, residual=x, kv=memory_kv)
+        x = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
+                       residual=x)
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):
         if memory_mask is not None:
@@ -104,6 +122,17 @@ class TransformerDecoder(nn.Module):
     def project_memory(self, memory):
         """Per-layer K/V projections of a memory (constant across greedy steps)."""
         return [layer.multihead_attn.project_memory(memory) for layer in self.layers]
+
+    def new_self_cache(self, batch, max_len, like):
+        E = self.layers[0].self_attn.embed_dim
+        return [torch.zeros(batch, max_len, 2 * E, dtype=like.dtype, device=like.device) for _ in self.layers]
+
+    def step(self, x, t, self_kvs, hist_valid, memory_kvs, memory_valid):
+        for layer, skv, mkv in zip(self.layers, self_kvs, memory_kvs):
+            x = layer.step(x, t, skv, hist_valid, mkv, memory_valid)
+        if self.norm is not None:
+            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):

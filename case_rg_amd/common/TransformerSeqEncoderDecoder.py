@@ -98,6 +98,42 @@ class PointerDecoderCore(nn.Module):
             copies.append(p)
         return dec_in, x, ctxs, copies
 
+    def _greedy(self, mems, valid, weights, source_map, BOS, max_target_length, feature_of=None):
+        """KV-cached greedy decoding (K13).  Step semantics are the reference's (CaSE/Model.py:94-123): fixed number of steps,
+        argmax of the newest position with the lowest index on ties, PAD tokens in the prefix masked as keys -- but each step
+        computes ONE new position: self-attention K/V of earlier positions, the per-layer K/V projections of both memories and
+        the additive-attention keys are cached, so a step streams the caches once instead of recomputing the prefix
+        (O(T) instead of O(T^2) decoder work, no per-step projection of the 3840-token passage memory)."""
+        B, dev = mems[0].shape[0], mems[0].device
+        cache = self._memory_cache(mems)
+        self_kvs = [dec.new_self_cache(B, max_target_length, mems[0]) for dec in self.decs]
+        hist_valid = torch.zeros(B, max_target_length, dtype=torch.bool, device=dev)
+        table, pos = self.embedding[0].weight, self.embedding[1]
+        if max_target_length > pos.pe.size(0):
+            raise RuntimeError("max_target_length %d exceeds max_len %d" % (max_target_length, pos.pe.size(0)))
+        ids = self._bos(B, BOS, dev)
+        feat = None if feature_of is None else feature_of(1)
+        picked = []
+        for t in range(max_target_length):
+            tok_valid = ids.ne(0)
+            hist_valid[:, t] = tok_valid[:, 0]
+            dec_in = ops.embed_pos(ids, table, pos.pe[t:t + 1])  # position t
+            x = dec_in
+            ctxs, copies = [], []
+            for i, mem in enumerate(mems):
+                x = self.decs[i].step(x, t, self_kvs[i], hist_valid, cache[i]["kvs"], valid[i])
+                q = x if feat is None else torch.cat([x, feat], dim=-1)
+                ctx, p = self.attns[i].attend(q, mem, mem, row_valid=tok_valid, col_valid=valid[i], uh=cache[i]["uh"])
+                ctxs.append(ctx)
+                if weights is not None:
+                    p = weights[i].unsqueeze(1) * p
+                    p = p / (1e-8 + p.sum(dim=-1, keepdim=True))
+                copies.append(p)
+            dec_out, gen, dist = self._head(dec_in, x, ctxs, copies, feat, source_map)
+            ids = ops.row_argmax(dist[:, -1])[0].unsqueeze(1)
+            picked.append(ids)
+        return dec_out, gen, dist, torch.cat(picked, dim=-1)
+
     def _generate(self, gen_in, hidden_drop):
         """gen = softmax(W_v (drop(W_h x + b)))  -- f32 logits and probabilities (K10)."""
         h = ops.linear(gen_in, self.gen[0].weight, self.gen[0].bias, p_drop=config.drop_p(hidden_drop, self.training))
@@ -137,12 +173,15 @@ class TransformerSeqDecoder(PointerDecoderCore):
         self.gen = nn.Sequential(nn.Linear(2 * H, H), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))
         self.mix = nn.Linear(H + num_memories * H, num_memories + 1)
 
-    def _step(self, dec_ids, mems, valid, weights, source_map, cache=None):
-        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, None, cache)
+    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
         dec_out = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         gen = self._generate(torch.cat([dec_in, dec_out], dim=-1), 0.0)
         d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
         return dec_out, gen, d1 + d2
+
+    def _step(self, dec_ids, mems, valid, weights, source_map, cache=None):
+        dec_in, x, ctxs, copies = self._run_prefix(dec_ids, mems, valid, weights, None, cache)
+        return self._head(dec_in, x, ctxs, copies, None, source_map)
 
     def _source(self, source_maps):
         return torch.cat(source_maps, dim=-2 if source_maps[0].dim() == 3 else -1)
@@ -161,10 +200,4 @@ class TransformerSeqDecoder(PointerDecoderCore):
             return dec_out, gen, dist, groundtruth_index
         if self.training:
             return None
-        cache = self._memory_cache(mems)
-        picked = []
-        for _ in range(max_target_length):
-            dec_ids = torch.cat([bos] + picked, dim=-1)
-            dec_out, gen, dist = self._step(dec_ids, mems, valid, weights, source_map, cache)
-            picked.append(ops.row_argmax(dist[:, -1])[0].unsqueeze(1))
-        return dec_out, gen, dist, torch.cat(picked, dim=-1)
+        return self._greedy(mems, valid, weights, source_map, BOS, max_target_length)
