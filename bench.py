@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the BASELINE workload keeps dropout on")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
     ap.add_argument("--mode", default="train", choices=["train", "decode"],
                     help="train: tokens/s of the training step (default, BASELINE cfg 2); decode: greedy answers/s (cfg 4)")
@@ -95,7 +96,7 @@ def build(a, device):
     from case_rg_amd.utils import make_vocab, synth_batch
 
     case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
-    case_rg_amd.set_dropout(True)
+    case_rg_amd.set_dropout(not a.no_dropout)
     init_seed(123456)  # the reference's seed (CaSE/Run.py:92)
     v2i, i2v = make_vocab(a.vocab)
     if a.model == "case":
@@ -291,9 +292,9 @@ def main():
         "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "%s train step fwd+bwd+allreduce+clip+Adam+EMA, d_model=%d, %d encoder layers, %d passages x %d tok, "
-                               "query %d, answer %d, vocab %d, per-GPU batch %d, dropout on" % (
+                               "query %d, answer %d, vocab %d, per-GPU batch %d, dropout %s" % (
                                    "CaSE" if a.model == "case" else "Masque", a.hidden, a.enc_layers, a.passages, a.passage_len,
-                                   a.query_len, a.answer_len, a.vocab, a.batch),
+                                   a.query_len, a.answer_len, a.vocab, a.batch, "off (diagnostic)" if a.no_dropout else "on"),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                    "algorithmic_tflop_per_step": round(3 * fwd * world / 1e12, 2)},
         "step_mfma_frac": round(3 * fwd / (elapsed / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -66,14 +66,18 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
-// Counter-based RNG (splitmix64 finaliser over seed/offset/index): uniform in [0,1).
-// Keyed by element index so forward and backward regenerate the same keep mask.
+// Counter-based RNG: uniform in [0,1) from (seed, 64-bit element index), keyed by element index so forward and backward
+// (and the fused / unfused attention paths) regenerate the same keep mask.  Two rounds of 32-bit multiply-xorshift
+// (murmur3-style finaliser): a 64-bit splitmix costs eight quarter-rate 32-bit multiplies per element, which made the
+// dropout epilogue of the short-K GEMMs as expensive as their MFMA work; this one costs two.
 __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = lo ^ ((hi << 16) | (hi >> 16)) ^ (uint32_t)seed;
+  h *= 0x9E3779B1u;
+  h ^= (h >> 15) ^ (uint32_t)(seed >> 32);
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
