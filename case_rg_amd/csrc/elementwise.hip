@@ -45,6 +45,85 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   if (ry == 0 && col < cols) atomicAdd(out + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
 }
 
+// ---- 16-byte vector variants (taken when the pointers are 16-byte aligned and the row width is a multiple of the vector) --
+// column sums: workgroup = 32 column chunks (of E columns) x 8 row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                         int64_t cols, int row_splits) {
+  constexpr int E = Vec16<T>::N;
+  __shared__ float part[8][32 * E + 1];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int64_t col = ((int64_t)(blockIdx.x / row_splits) * 32 + cx) * E;
+  const int split = blockIdx.x % row_splits;
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  if (col < cols)
+    for (int64_t r = (int64_t)split * 8 + ry; r < rows; r += (int64_t)row_splits * 8) {
+      float v[E];
+      Vec16<T>::load(x + r * cols + col, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < E; ++e) part[ry][cx * E + e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 32 * E; c += 256) {
+    const int64_t gc = (int64_t)(blockIdx.x / row_splits) * 32 * E + c;
+    if (gc < cols) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += part[r][c];
+      atomicAdd(out + gc, t);
+    }
+  }
+}
+
+template <typename T>
+__global__ void add_vec_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t nvec) {
+  constexpr int E = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float x[E], y[E];
+    Vec16<T>::load(a + i * E, x);
+    Vec16<T>::load(b + i * E, y);
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] += y[e];
+    Vec16<T>::store(o + i * E, x);
+  }
+}
+
+template <typename T>
+__global__ void dropout_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t nvec, float p, uint64_t seed,
+                                   uint64_t offset) {
+  constexpr int E = Vec16<T>::N;
+  const float scale = 1.f / (1.f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[E];
+    Vec16<T>::load(x + i * E, v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = rng_uniform(seed, offset + (uint64_t)(i * E + e)) >= p ? v[e] * scale : 0.f;
+    Vec16<T>::store(y + i * E, v);
+  }
+}
+
+template <typename T>
+__global__ void mask_rows_vec_kernel(const T* __restrict__ x, const uint8_t* __restrict__ valid, T* __restrict__ y,
+                                     int64_t rows, int64_t cols) {
+  constexpr int E = Vec16<T>::N;
+  const int64_t vpr = cols / E, nvec = rows * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[E];
+    if (valid[i / vpr]) Vec16<T>::load(x + i * E, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = 0.f;
+    }
+    Vec16<T>::store(y + i * E, v);
+  }
+}
+
+static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ x, TD* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -268,18 +347,27 @@ __global__ void max_over_p_bwd_kernel(const T* __restrict__ d_out, const int32_t
 
 extern "C" int case_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(a && b && out && n > 0, "case_add: bad argument");
+  const int ev = dtype == CASE_BF16 ? 8 : 4;
+  if (n % ev == 0 && al16(a) && al16(b) && al16(out))
+    EW_DISPATCH("case_add", n / ev, add_vec_kernel, (const T*)a, (const T*)b, (T*)out, n / ev);
   EW_DISPATCH("case_add", n, add_kernel, (const T*)a, (const T*)b, (T*)out, n);
 }
 
 extern "C" int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,
                             case_stream_t stream) {
   CASE_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "case_dropout: bad argument");
+  const int ev = dtype == CASE_BF16 ? 8 : 4;
+  if (n % ev == 0 && al16(x) && al16(y))
+    EW_DISPATCH("case_dropout", n / ev, dropout_vec_kernel, (const T*)x, (T*)y, n / ev, p, seed, offset);
   EW_DISPATCH("case_dropout", n, dropout_kernel, (const T*)x, (T*)y, n, p, seed, offset);
 }
 
 extern "C" int case_mask_rows(const void* x, const uint8_t* row_valid, void* y, int64_t rows, int64_t cols,
                               int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(x && row_valid && y && rows > 0 && cols > 0, "case_mask_rows: bad argument");
+  const int ev = dtype == CASE_BF16 ? 8 : 4;
+  if (cols % ev == 0 && al16(x) && al16(y))
+    EW_DISPATCH("case_mask_rows", rows * cols / ev, mask_rows_vec_kernel, (const T*)x, row_valid, (T*)y, rows, cols);
   EW_DISPATCH("case_mask_rows", rows * cols, mask_rows_kernel, (const T*)x, row_valid, (T*)y, rows, cols);
 }
 
@@ -293,6 +381,20 @@ static int colsum_splits(int64_t rows, int64_t cols) {
 
 extern "C" int case_colsum(const void* x, float* out, int64_t rows, int64_t cols, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(x && out && rows > 0 && cols > 0, "case_colsum: bad argument");
+  {
+    const int ev = dtype == CASE_BF16 ? 8 : 4;
+    if (cols % ev == 0 && al16(x)) {
+      const int64_t col_blocks = (cols + 32 * ev - 1) / (32 * ev);
+      int64_t want = 2048 / col_blocks, cap = (rows + 63) / 64;
+      if (want > cap) want = cap;
+      if (want < 1) want = 1;
+      const int vsplits = (int)want;
+      hipStream_t vs = (hipStream_t)stream;
+      if (dtype == CASE_F32) hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3((unsigned)(col_blocks * vsplits)), dim3(256), 0, vs, (const float*)x, out, rows, cols, vsplits);
+      else hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3((unsigned)(col_blocks * vsplits)), dim3(256), 0, vs, (const bf16_t*)x, out, rows, cols, vsplits);
+      return case_check_launch("case_colsum");
+    }
+  }
   const int splits = colsum_splits(rows, cols);
   const int grid = (int)((cols + 63) / 64) * splits;
   hipStream_t s = (hipStream_t)stream;
