@@ -56,6 +56,8 @@ SIGNATURES = {
     "case_cast": [ptr, ptr, i64, i32, i32, ptr],
     "case_scale_cols": [ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_scale_cols_bwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_rowdot_fwd": [ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_rowdot_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_masked_mean_fwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
     "case_masked_mean_bwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
     "case_highway_gate_fwd": [ptr, ptr, i64, i64, i32, ptr],

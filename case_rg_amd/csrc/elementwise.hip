@@ -122,6 +122,54 @@ __global__ void mask_rows_vec_kernel(const T* __restrict__ x, const uint8_t* __r
   }
 }
 
+// ---- single-output linear (Linear(H, 1): passage / token scorers, Interaction rank-1 terms) ---------------------------
+// y[r] = x[r, :] . w (+ b): one wave per row, 16-byte loads, shuffle reduction -- an N = 1 GEMM tile would waste 127/128
+// of the MFMA work and cannot use vector loads for its gradient operand.
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int64_t rows,
+                                                         int64_t cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    float acc = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) acc += Elem<T>::ld(x + r * cols + c) * w[c];
+    acc = wave_sum(acc);
+    if (lane == 0) y[r] = acc + (b ? b[0] : 0.f);
+  }
+}
+
+// dx[r, :] = g[r] * w ; dw[c] += sum_r g[r] * x[r, c] ; db += sum_r g[r]   (column tiling as colsum)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ g, const T* __restrict__ x,
+                                                         const float* __restrict__ w, T* __restrict__ dx,
+                                                         float* __restrict__ dw, float* __restrict__ db, int64_t rows,
+                                                         int64_t cols, int row_splits) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t col = (int64_t)(blockIdx.x / row_splits) * 64 + cx;
+  const int split = blockIdx.x % row_splits;
+  float s = 0.f, sb = 0.f;
+  if (col < cols) {
+    const float wc = w[col];
+    for (int64_t r = (int64_t)split * 4 + ry; r < rows; r += (int64_t)row_splits * 4) {
+      const float gr = g[r];
+      s += gr * Elem<T>::ld(x + r * cols + col);
+      sb += gr;
+      if (dx) Elem<T>::st(dx + r * cols + col, gr * wc);
+    }
+  }
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) atomicAdd(dw + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+  if (db && col == 0) {
+    __syncthreads();
+    part[ry][0] = sb;
+    __syncthreads();
+    if (ry == 0 && cx == 0) atomicAdd(db, part[0][0] + part[1][0] + part[2][0] + part[3][0]);
+  }
+}
+
 static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 template <typename TS, typename TD>
@@ -504,4 +552,27 @@ extern "C" int case_max_over_p_bwd(const void* d_out, const int32_t* argmax, voi
                                    int64_t inner, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(d_out && argmax && dx && B > 0 && P > 0 && inner > 0, "case_max_over_p_bwd: bad argument");
   EW_DISPATCH("case_max_over_p_bwd", B * P * inner, max_over_p_bwd_kernel, (const T*)d_out, argmax, (T*)dx, B, P, inner);
+}
+
+extern "C" int case_rowdot_fwd(const void* x, const float* w, const float* b, float* y, int64_t rows, int64_t cols,
+                               int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(x && w && y && rows > 0 && cols > 0, "case_rowdot_fwd: bad argument");
+  const int grid = grid_for(rows, 4, 2, 256 * 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32) hipLaunchKernelGGL(rowdot_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, b, y, rows, cols);
+  else if (dtype == CASE_BF16) hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, b, y, rows, cols);
+  else return case_set_error(CASE_E_UNSUPPORTED, "case_rowdot_fwd: dtype %d", dtype);
+  return case_check_launch("case_rowdot_fwd");
+}
+
+extern "C" int case_rowdot_bwd(const float* g, const void* x, const float* w, void* dx, float* dw, float* db, int64_t rows,
+                               int64_t cols, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(g && x && w && dw && rows > 0 && cols > 0, "case_rowdot_bwd: bad argument");
+  const int splits = colsum_splits(rows, cols);
+  const int grid = (int)((cols + 63) / 64) * splits;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CASE_F32) hipLaunchKernelGGL(rowdot_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, g, (const float*)x, w, (float*)dx, dw, db, rows, cols, splits);
+  else if (dtype == CASE_BF16) hipLaunchKernelGGL(rowdot_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, g, (const bf16_t*)x, w, (bf16_t*)dx, dw, db, rows, cols, splits);
+  else return case_set_error(CASE_E_UNSUPPORTED, "case_rowdot_bwd: dtype %d", dtype);
+  return case_check_launch("case_rowdot_bwd");
 }

@@ -191,7 +191,39 @@ class LinearFn(Function):
         return dx, dw, db, d_res, None, None
 
 
+class RowDotFn(Function):
+    """Linear with ONE output feature: y[..., 0] = x . w + b (f32 out)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        wv = w.detach().reshape(-1).float().contiguous()
+        bv = None if b is None else b.detach().reshape(-1).float().contiguous()
+        y = torch.empty(x2.shape[0], dtype=torch.float32, device=x2.device)
+        A.call("case_rowdot_fwd", _ptr(x2), _ptr(wv), _ptr(bv), _ptr(y), x2.shape[0], C, _code(x2), _stream())
+        ctx.save_for_backward(x2, wv)
+        ctx.meta = (x.shape, w.shape, b is not None)
+        return y.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, wv = ctx.saved_tensors
+        xshape, wshape, has_b = ctx.meta
+        R, C = x2.shape
+        g = g.reshape(-1).float().contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros(C, dtype=torch.float32, device=x2.device)
+        db = torch.zeros(1, dtype=torch.float32, device=x2.device) if has_b else None
+        A.call("case_rowdot_bwd", _ptr(g), _ptr(x2), _ptr(wv), _ptr(dx), _ptr(dw), _ptr(db), R, C, _code(x2), _stream())
+        return (None if dx is None else dx.view(xshape)), dw.view(wshape), db
+
+
 def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None):
+    if w.shape[0] == 1 and residual is None and p_drop == 0.0 and out_dtype in (None, torch.float32) and (
+            out_dtype is torch.float32 or x.dtype == torch.float32):
+        return RowDotFn.apply(x, w, b)  # single-output heads: a row dot, not an N = 1 GEMM tile
     return LinearFn.apply(x, w, b, residual, p_drop, out_dtype)
 
 

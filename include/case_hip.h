@@ -189,6 +189,13 @@ int case_scale_cols(const void* x, const float* w, void* y, int64_t rows, int64_
                     case_stream_t stream);
 int case_scale_cols_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int64_t rows,
                         int64_t cols, int32_t dtype, case_stream_t stream);
+/* single-output linear y[r] = x[r, :] . w (+ b[0]): the scorers (CaSE/Model.py:161,201, Masque/Model.py:157) and the
+ * rank-1 terms of the Interaction score (common/Interaction.py:36).  y, g f32 [rows]; w f32 [cols].
+ * bwd: dx[r, :] = g[r] * w (dx may be null), dw[c] += sum_r g[r] x[r, c], db[0] += sum_r g[r] (dw / db pre-zeroed). */
+int case_rowdot_fwd(const void* x, const float* w, const float* b, float* y, int64_t rows, int64_t cols, int32_t dtype,
+                    case_stream_t stream);
+int case_rowdot_bwd(const float* g, const void* x, const float* w, void* dx, float* dw, float* db, int64_t rows,
+                    int64_t cols, int32_t dtype, case_stream_t stream);
 /* masked mean over the sequence: common/Utils.py:455-470.  x [n, L, H], valid u8 [n, L] -> out [n, H] */
 int case_masked_mean_fwd(const void* x, const uint8_t* valid, void* out, int64_t n, int64_t L, int64_t H,
                          int32_t dtype, case_stream_t stream);
