@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the BASELINE workload keeps dropout on")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
-    ap.add_argument("--mode", default="train", choices=["train", "decode"],
-                    help="train: tokens/s of the training step (default, BASELINE cfg 2); decode: greedy answers/s (cfg 4)")
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "encoder"],
+                    help="train: tokens/s of the training step (default, BASELINE cfg 2); decode: greedy answers/s (cfg 4); "
+                         "encoder: the north-star point, TransformerSeqEncoder forward at batch x passages x passage-len")
     ap.add_argument("--decode-len", type=int, default=64)
     ap.add_argument("--graph", action="store_true", help="decode: replay the whole greedy pass from one captured hipGraph")
     return ap.parse_args()
@@ -242,6 +243,36 @@ def decode_main(a, device, world, rank):
         print(json.dumps(res))
 
 
+def encoder_main(a, device):
+    """North-star point: CaSE encoder forward, B x P x Lp tokens, fraction of the bf16 MFMA roofline."""
+    import case_rg_amd
+    from case_rg_amd.common.CumulativeTrainer import init_params
+    from case_rg_amd.common.TransformerSeqEncoderDecoder import TransformerSeqEncoder
+    from case_rg_amd.utils import synth_batch
+    case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    enc = TransformerSeqEncoder(a.enc_layers, 8, a.vocab, a.hidden)
+    init_params(enc)
+    enc = enc.to(device).eval()
+    ids = synth_batch(a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, ragged=False)["passage"].to(device)
+    with torch.no_grad():
+        for _ in range(max(1, a.warmup)):
+            enc(ids)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            enc(ids)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    L, H, n = a.passage_len, a.hidden, a.batch * a.passages
+    flops = a.enc_layers * n * (12 * L * H * H + 4 * L * L * H)
+    print(json.dumps({"metric": "CaSE encoder forward (north-star point)", "value": round(n * L / dt, 1), "unit": "tokens/s", "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": a.dtype,
+                      "data": "synthetic", "config": {"workload": "TransformerSeqEncoder forward, %d layers, d_model %d, %d x %d x %d tokens" % (
+                          a.enc_layers, H, a.batch, a.passages, L)},
+                      "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_tflop": round(flops / 1e12, 3)}}))
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,6 +284,10 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
+    if a.mode == "encoder":
+        if rank == 0:
+            encoder_main(a, device)
+        return
     if a.mode == "decode":
         decode_main(a, device, world, rank)
         if world > 1:

@@ -129,3 +129,56 @@ def test_reference_checkpoint_schema_loads_strict(ns):
     src = fill_params(oracle.CaSE(4, 6, i2v, v2i, 32), 3)
     dst = ns.CaSE(4, 6, i2v, v2i, 32)
     dst.load_state_dict(src.state_dict(), strict=True)
+
+
+def test_error_behaviour_mirrors_the_reference(ns):
+    """RuntimeError for an unknown activation (TransformerEncoder.py:17), assertion for num_q not in {1, num_p}
+    (Interaction.py:27), and a loud error instead of an out-of-bounds read past the sinusoid table (max_len 1000)."""
+    with pytest.raises(RuntimeError, match="relu/gelu"):
+        ns.TransformerEncoderLayer(32, 8, 32, activation="swish")
+    inter = ns.Interaction(32).cuda()
+    e2 = torch.zeros(2, 2, 4, 32, device="cuda")
+    e3 = torch.zeros(2, 3, 5, 32, device="cuda")
+    with pytest.raises(AssertionError):
+        inter(e2, e3, torch.ones(2, 2, 4, dtype=torch.bool, device="cuda"), torch.ones(2, 3, 5, dtype=torch.bool, device="cuda"))
+    enc = ns.TransformerSeqEncoder(1, 8, 120, 32).cuda()
+    with pytest.raises(RuntimeError, match="max_len"):
+        enc(torch.ones(1, 1, 1001, dtype=torch.long, device="cuda"))
+
+
+def test_full_size_properties_cfg2_shapes(ns):
+    """Size-independent properties at the BASELINE cfg 2 shapes (one batch item, 10 x 384 passages, H = 512, bf16):
+    padded positions come out exactly zero, the copy distribution carries probability mass only on source ids, every
+    distribution row sums to 1, and appending padding to every passage does not change the losses."""
+    import case_rg_amd
+    from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+    case_rg_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        V = 2000
+        v2i, i2v = make_vocab(V)
+        model = fill_params(ns.CaSE(4, 40, i2v, v2i, 512), 3).cuda().train()
+        b = {k: v.cuda() for k, v in synth_batch(1, 10, 384, 64, 40, V, seed=5, model="case").items()}
+        with torch.no_grad():
+            eq, ep = model.query_encoder(b["query"]), model.passage_encoder(b["passage"])
+            ps = model.passage_selection.action(b["query"], b["passage"], encode_query=eq, encode_passage=ep)
+            se = model.span_extraction.action(b["query"], b["passage"], encode_query=eq, encode_passage=ep, passage_selection_result=ps)
+            pad = b["passage"].eq(0)
+            assert pad.any() and (ps[2][0][pad] == 0).all(), "selection-stage reps must be exactly zero at pads"
+            rg = model.response_generation.action(b["query"], b["passage"], b["source_map"], eq, ep, ps, se, output=b["response"])
+            d1, d2 = rg[2]
+            total = (d1 + d2).sum(-1)
+            assert torch.allclose(total, torch.ones_like(total), atol=2e-2), "distribution rows must sum to 1"
+            off_source = torch.ones(V, dtype=torch.bool, device="cuda")
+            off_source[b["source_map"][0]] = False
+            assert (d2[0][:, off_source] == 0).all(), "copy mass outside the source ids"
+            base = [l.item() for l in model(dict(b), method="train")]
+            wider = dict(b)
+            wider["passage"] = torch.nn.functional.pad(b["passage"], (0, 16))
+            wider["token_label"] = torch.nn.functional.pad(b["token_label"], (0, 16))
+            wider["token_weight"] = torch.nn.functional.pad(b["token_weight"], (0, 16), value=1.0)
+            wider["source_map"] = torch.cat([b["query"].reshape(1, -1), wider["passage"].reshape(1, -1)], 1)
+            more = [l.item() for l in model(wider, method="train")]
+            for x, y in zip(base, more):
+                assert abs(x - y) <= 3e-2 * max(1.0, abs(x)), (base, more)
+    finally:
+        case_rg_amd.set_compute_dtype(torch.float32)
