@@ -13,13 +13,17 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None):
+    def __init__(self, model, bucket_mb=64, process_group=None, force=False):
+        """``force`` keeps the bucket / hook / collective machinery active on a one-rank group (used by the GPU test that
+        drives the RCCL path on a single device)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []  # [flat buffer, [(param, offset, numel)], pending count, work handle]
         self._slot = {}
-        if self.world == 1:
+        self._armed = False
+        self.active = dist.is_initialized() and (self.world > 1 or force)
+        if not self.active:
             return
         cap = int(bucket_mb * (1 << 20) // 4)
         cur, cur_n = [], 0
@@ -70,7 +74,7 @@ class GradSync:
     def finish(self):
         """Wait for every bucket, average, write the reduced gradients back.  Buckets whose hooks did not all fire
         (parameters unused this step) are reduced here with zeros for the missing gradients."""
-        if self.world == 1 or not self._armed:
+        if not self.active or not self._armed:
             return
         for b in self.buckets:
             if b["work"] is None:

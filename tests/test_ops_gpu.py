@@ -337,3 +337,18 @@ def test_fused_attention_matches_unfused_and_reference(N, h, Lq, Lk, d, causal):
                 _close(gf, gu, 4e-2, "fused vs unfused gradients with dropout")
     finally:
         config.set_dropout(False)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_k_tile_counts(dt):
+    """Every K-loop shape of the software pipeline: 1, 2, 3 (tail paths), 4, 5, 7 and 16 K tiles, full and edge tiles."""
+    ops = _ops()
+    per_tile = 32 if dt == torch.float32 else 64
+    for tiles in (1, 2, 3, 4, 5, 7, 16):
+        for (M, N) in ((128, 128), (16, 192), (200, 130)):
+            K = tiles * per_tile
+            x = _rand(M, K, dt=dt, seed=tiles)
+            w = _rand(N, K, seed=100 + tiles, scale=K ** -0.5)
+            y = ops.linear(x, w, None)
+            ref = F.linear(x.float(), w.to(dt).float())
+            _close(y, ref, _tol(dt), "gemm K=%d M=%d N=%d" % (K, M, N))

@@ -182,3 +182,37 @@ def test_full_size_properties_cfg2_shapes(ns):
                 assert abs(x - y) <= 3e-2 * max(1.0, abs(x)), (base, more)
     finally:
         case_rg_amd.set_compute_dtype(torch.float32)
+
+
+def test_gradsync_over_rccl_on_one_rank(ns):
+    """Drives the data-parallel machinery (post-accumulate hooks -> flat buckets -> asynchronous RCCL all-reduce ->
+    scatter back) on a one-rank "nccl" group on the GPU: the synchronised gradients must equal the plain ones."""
+    import socket
+    import torch.distributed as dist
+    from case_rg_amd.parallel import GradSync
+    from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        v2i, i2v = make_vocab(300)
+        model = fill_params(ns.Masque(6, i2v, v2i, 64), 4).cuda().train()
+        b = {k: v.cuda() for k, v in synth_batch(2, 3, 16, 8, 6, 300, seed=8, model="masque").items()}
+        sum(l.mean() for l in model(dict(b), method="train")).backward()
+        plain = {n: p.grad.clone() for n, p in model.named_parameters()}
+        model.zero_grad()
+        sync = GradSync(model, bucket_mb=0.25, force=True)
+        assert sync.active and len(sync.buckets) > 2
+        sum(l.mean() for l in model(dict(b), method="train")).backward()
+        sync.finish()
+        torch.cuda.synchronize()
+        # f32 atomics (embedding rows, split-K weight gradients) make two runs differ in the last bits
+        for n, p in model.named_parameters():
+            scale = plain[n].abs().max().item() + 1e-12
+            err = (p.grad - plain[n]).abs().max().item()
+            assert err <= 1e-4 * scale, "%s: %.3e vs scale %.3e" % (n, err, scale)
+    finally:
+        dist.destroy_process_group()
