@@ -70,6 +70,40 @@ __global__ __launch_bounds__(256) void additive_fwd_kernel(const float* __restri
   }
 }
 
+// Few target rows (greedy decoding: T = 1 per step): one wave per source position j, lanes = h (16-byte coalesced read of
+// the uh row, no LDS transpose), shuffle reduction of the H-sum.  The tiled kernel above would spend 31/32 of its tanh work
+// on absent target rows; this one is bound by streaming uh once (B*S*H*esz bytes).
+template <typename T, bool FAST, int TT>
+__global__ __launch_bounds__(256) void additive_fwd_rowwise_kernel(const float* __restrict__ wq, const T* __restrict__ uh,
+                                                                   const float* __restrict__ v, float* __restrict__ s,
+                                                                   int64_t Tn, int64_t S, int64_t H) {
+  constexpr int E = Vec16<T>::N;
+  const int64_t b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t j = wave; j < S; j += nwaves) {
+    float acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+    for (int64_t h0 = (int64_t)lane * E; h0 < H; h0 += 64 * E) {
+      float u[E];
+      Vec16<T>::load(uh + (b * S + j) * H + h0, u);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float vv = v[h0 + e];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+          if (t < Tn) acc[t] += vv * tanh_t<FAST>(wq[(b * Tn + t) * H + h0 + e] + u[e]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const float r = wave_sum(acc[t]);
+      if (lane == 0 && t < Tn) s[(b * Tn + t) * S + j] = r;
+    }
+  }
+}
+
 // sweep 1: thread owns h (256 per workgroup), workgroup owns BJ source positions; sums over t.
 constexpr int BJ = 16;
 constexpr int BTC = 32;  // t chunk staged in LDS
@@ -252,8 +286,17 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
 extern "C" int case_additive_scores_fwd(const float* wq, const void* uh, const float* v, float* s, int64_t B, int64_t T,
                                         int64_t S, int64_t H, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(wq && uh && v && s && B > 0 && T > 0 && S > 0 && H > 0 && B < 65536, "case_additive_scores_fwd: bad argument");
-  const dim3 grid((unsigned)((S + AJ - 1) / AJ), (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
+  const int ev = dtype == CASE_F32 ? 4 : 8;
+  if (T <= 4 && H % ev == 0 && (uintptr_t)uh % 16 == 0) {  // decode steps
+    const dim3 g((unsigned)((S + 15) / 16 < 64 ? (S + 15) / 16 : 64), (unsigned)B);
+    if (dtype == CASE_F32)
+      hipLaunchKernelGGL((additive_fwd_rowwise_kernel<float, false, 4>), g, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
+    else
+      hipLaunchKernelGGL((additive_fwd_rowwise_kernel<bf16_t, true, 4>), g, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
+    return case_check_launch("case_additive_scores_fwd");
+  }
+  const dim3 grid((unsigned)((S + AJ - 1) / AJ), (unsigned)B);
   if (dtype == CASE_F32)
     hipLaunchKernelGGL((additive_fwd_kernel<float, false>), grid, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
   else

@@ -352,3 +352,15 @@ def test_gemm_k_tile_counts(dt):
             y = ops.linear(x, w, None)
             ref = F.linear(x.float(), w.to(dt).float())
             _close(y, ref, _tol(dt), "gemm K=%d M=%d N=%d" % (K, M, N))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [1, 3])
+def test_additive_scores_decode_rows(dt, T):
+    """T <= 4 takes the row-wise (decode-step) kernel."""
+    ops = _ops()
+    B, S, H = 3, 77, 128
+    wq, uh, v = _rand(B, T, H, seed=1), _rand(B, S, H, dt=dt, seed=2), _rand(H, seed=3)
+    s = ops.additive_scores(wq, uh, v)
+    ref = torch.tanh(wq[:, :, None, :] + uh.float()[:, None, :, :]) @ v
+    _close(s, ref, 1e-3 if dt == torch.float32 else 1e-2, "additive decode rows")
