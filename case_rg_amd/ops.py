@@ -5,6 +5,7 @@ arithmetic pass over an activation is a kernel of libcase_hip.so launched throug
 stream.  There is no eager fallback: tensors must live on a ROCm device.
 """
 import math
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -49,19 +50,25 @@ _cast_cache = {}
 
 
 def cast_param(p, dtype):
-    """fp32 parameter -> operand of the compute dtype.  bf16 copies are cached until the parameter is
-    updated in place (optimizer step bumps ``_version``)."""
+    """fp32 parameter -> operand of the compute dtype.  bf16 copies of nn.Parameters (and of views of them, e.g. the K/V rows
+    of ``in_proj_weight``) are cached until the parameter is updated in place (the optimizer step bumps ``_version``).  The
+    cache is keyed by the owning Parameter object, held through a weak reference: temporaries (``torch.cat`` of weights, test
+    tensors) are never cached -- a freed tensor's address can be handed to a new tensor of the same shape."""
     src = p.detach()
     if src.dtype == dtype:
         return src if src.is_contiguous() else src.contiguous()
-    key = (src.data_ptr(), tuple(src.shape), dtype)
+    base = getattr(p, "_base", None)
+    owner = p if isinstance(p, torch.nn.Parameter) else (base if isinstance(base, torch.nn.Parameter) else None)
+    if owner is None:
+        return cast(src, dtype)
+    key = (id(owner), src.storage_offset(), tuple(src.shape), tuple(src.stride()), dtype)
     hit = _cast_cache.get(key)
-    if hit is not None and hit[0] == p._version:
-        return hit[1]
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
+        return hit[2]
     src = src.contiguous()
     out = torch.empty(src.shape, dtype=dtype, device=src.device)
     A.call("case_cast", _ptr(src), _ptr(out), src.numel(), _code(src), _DT[dtype], _stream())
-    _cast_cache[key] = (p._version, out)
+    _cast_cache[key] = (weakref.ref(owner), owner._version, out)
     return out
 
 

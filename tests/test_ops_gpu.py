@@ -364,3 +364,22 @@ def test_additive_scores_decode_rows(dt, T):
     s = ops.additive_scores(wq, uh, v)
     ref = torch.tanh(wq[:, :, None, :] + uh.float()[:, None, :, :]) @ v
     _close(s, ref, 1e-3 if dt == torch.float32 else 1e-2, "additive decode rows")
+
+
+def test_cast_cache_is_not_fooled_by_address_reuse():
+    """bf16 operand copies are cached for Parameters only; a temporary weight at a recycled address must not hit the cache."""
+    ops = _ops()
+    x = _rand(64, 64, dt=torch.bfloat16, seed=1)
+    outs = []
+    for seed in (2, 3, 4):
+        w = _rand(64, 64, seed=seed)  # freed at the end of the iteration: the allocator hands the address out again
+        outs.append((ops.linear(x, w, None).float(), F.linear(x.float(), w.to(torch.bfloat16).float())))
+        del w
+    for got, want in outs:
+        _close(got, want, 3e-2, "temporary weight")
+    p = torch.nn.Parameter(_rand(64, 64, seed=9))
+    a = ops.linear(x, p, None).float()
+    with torch.no_grad():
+        p.mul_(2.0)  # in-place update bumps the version: the cached copy must be refreshed
+    b = ops.linear(x, p, None).float()
+    _close(b, 2 * a, 3e-2, "parameter update invalidates the cached copy")
