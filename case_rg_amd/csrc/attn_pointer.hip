@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void additive_fwd_kernel(const float* __restri
 // Few target rows (greedy decoding: T = 1 per step): one wave per source position j, lanes = h (16-byte coalesced read of
 // the uh row, no LDS transpose), shuffle reduction of the H-sum.  The tiled kernel above would spend 31/32 of its tanh work
 // on absent target rows; this one is bound by streaming uh once (B*S*H*esz bytes).
-template <typename T, bool FAST, int TT>
+template <typename T, bool FAST, int TT, int NCH>
 __global__ __launch_bounds__(256) void additive_fwd_rowwise_kernel(const float* __restrict__ wq, const T* __restrict__ uh,
                                                                    const float* __restrict__ v, float* __restrict__ s,
                                                                    int64_t Tn, int64_t S, int64_t H) {
@@ -81,19 +81,32 @@ __global__ __launch_bounds__(256) void additive_fwd_rowwise_kernel(const float* 
   const int64_t b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  // this lane's slice of the query projection and of v stays in registers for every source position
+  float wreg[NCH][TT][E], vreg[NCH][E];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int64_t h0 = ((int64_t)c * 64 + lane) * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      vreg[c][e] = h0 < H ? v[h0 + e] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) wreg[c][t][e] = (h0 < H && t < Tn) ? wq[(b * Tn + t) * H + h0 + e] : 0.f;
+    }
+  }
   for (int64_t j = wave; j < S; j += nwaves) {
     float acc[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[t] = 0.f;
-    for (int64_t h0 = (int64_t)lane * E; h0 < H; h0 += 64 * E) {
-      float u[E];
-      Vec16<T>::load(uh + (b * S + j) * H + h0, u);
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const float vv = v[h0 + e];
+    for (int c = 0; c < NCH; ++c) {
+      const int64_t h0 = ((int64_t)c * 64 + lane) * E;
+      if (h0 < H) {
+        float u[E];
+        Vec16<T>::load(uh + (b * S + j) * H + h0, u);
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
-          if (t < Tn) acc[t] += vv * tanh_t<FAST>(wq[(b * Tn + t) * H + h0 + e] + u[e]);
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+          for (int t = 0; t < TT; ++t) acc[t] += vreg[c][e] * tanh_t<FAST>(wreg[c][t][e] + u[e]);
       }
     }
 #pragma unroll
@@ -288,12 +301,16 @@ extern "C" int case_additive_scores_fwd(const float* wq, const void* uh, const f
   CASE_REQUIRE(wq && uh && v && s && B > 0 && T > 0 && S > 0 && H > 0 && B < 65536, "case_additive_scores_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int ev = dtype == CASE_F32 ? 4 : 8;
-  if (T <= 4 && H % ev == 0 && (uintptr_t)uh % 16 == 0) {  // decode steps
+  if (T <= 2 && H % ev == 0 && H <= 2 * 64 * ev && (uintptr_t)uh % 16 == 0) {  // decode steps (T = 1)
     const dim3 g((unsigned)((S + 15) / 16 < 64 ? (S + 15) / 16 : 64), (unsigned)B);
-    if (dtype == CASE_F32)
-      hipLaunchKernelGGL((additive_fwd_rowwise_kernel<float, false, 4>), g, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
-    else
-      hipLaunchKernelGGL((additive_fwd_rowwise_kernel<bf16_t, true, 4>), g, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
+    const bool one = H <= 64 * ev;
+    if (dtype == CASE_F32) {
+      if (one) hipLaunchKernelGGL((additive_fwd_rowwise_kernel<float, false, 2, 1>), g, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
+      else hipLaunchKernelGGL((additive_fwd_rowwise_kernel<float, false, 2, 2>), g, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
+    } else {
+      if (one) hipLaunchKernelGGL((additive_fwd_rowwise_kernel<bf16_t, true, 2, 1>), g, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
+      else hipLaunchKernelGGL((additive_fwd_rowwise_kernel<bf16_t, true, 2, 2>), g, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
+    }
     return case_check_launch("case_additive_scores_fwd");
   }
   const dim3 grid((unsigned)((S + AJ - 1) / AJ), (unsigned)B);

@@ -355,9 +355,9 @@ def test_gemm_k_tile_counts(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("T", [1, 3])
+@pytest.mark.parametrize("T", [1, 2])
 def test_additive_scores_decode_rows(dt, T):
-    """T <= 4 takes the row-wise (decode-step) kernel."""
+    """T <= 2 takes the row-wise (decode-step) kernel."""
     ops = _ops()
     B, S, H = 3, 77, 128
     wq, uh, v = _rand(B, T, H, seed=1), _rand(B, S, H, dt=dt, seed=2), _rand(H, seed=3)
