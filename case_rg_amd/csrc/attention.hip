@@ -125,14 +125,14 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds, int row0, int dt) {
   return r;
 }
 
-__device__ __forceinline__ short bf16_bits(float f) { return (short)f32_to_bf16(f); }
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // accumulator registers 8*s2 .. 8*s2+7 -> B-operand fragment of k-step s2
 __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
-  bf16x8 r;
+  u32x4_t w;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = bf16_bits(a[8 * s2 + j]);
-  return r;
+  for (int j = 0; j < 4; ++j) w[j] = f32x2_to_bf16x2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
+  return *reinterpret_cast<bf16x8*>(&w);
 }
 
 // stationary fragments: lane (c = l&31, h = l>>5) holds row (row0 + c), head-dim values 16 s + 8 h .. + 7
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const uint32_t w0 = (uint32_t)f32_to_bf16(o[dt][4 * g] * inv) | ((uint32_t)f32_to_bf16(o[dt][4 * g + 1] * inv) << 16);
-        const uint32_t w1 = (uint32_t)f32_to_bf16(o[dt][4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o[dt][4 * g + 3] * inv) << 16);
+        const uint32_t w0 = f32x2_to_bf16x2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+        const uint32_t w1 = f32x2_to_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = make_uint2(w0, w1);
       }
     if (half == 0) a.lse[((int64_t)n * a.heads + head) * a.Lq + qi] = lsum > 0.f ? m + __logf(lsum) : -INFINITY;
@@ -343,8 +343,8 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[D / 32], bf
   for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const uint32_t w0 = (uint32_t)f32_to_bf16(acc[dt][4 * g] * mul) | ((uint32_t)f32_to_bf16(acc[dt][4 * g + 1] * mul) << 16);
-      const uint32_t w1 = (uint32_t)f32_to_bf16(acc[dt][4 * g + 2] * mul) | ((uint32_t)f32_to_bf16(acc[dt][4 * g + 3] * mul) << 16);
+      const uint32_t w0 = f32x2_to_bf16x2(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul);
+      const uint32_t w1 = f32x2_to_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
       *reinterpret_cast<uint2*>(row_ptr + dt * 32 + 8 * g + 4 * half) = make_uint2(w0, w1);
     }
 }

@@ -16,12 +16,16 @@ int case_check_launch(const char* what);
   } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even, NaN stays a quiet NaN: gfx950's v_cvt_pk_bf16_f32 (one instruction per pair; the integer
+// formulation costs ~7 VALU per element, which was a third of the GEMM epilogue at one wave per SIMD)
+typedef float case_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 case_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+  const case_f32x2 v = {lo, hi};
+  const case_bf16x2 b = __builtin_convertvector(v, case_bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&b);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -59,7 +63,7 @@ template <> struct Vec16<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

@@ -47,8 +47,37 @@ struct Args {
 #undef GEMM_NS
 #undef GEMM_NTHREADS
 
+#include "gemm256.inc"
+
+#include <stdlib.h>
+
 namespace {
 constexpr int BM = 128, BN = 128, ROWB = 128;
+
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  return cus;
+}
+// 0 = 128x128 only, 1 = cost model, 2 = 256x256 whenever eligible; CASE_GEMM_TILE_POLICY presets it (A/B measurements)
+int g_tile_policy = -1;
+int tile_policy() {
+  if (g_tile_policy < 0) {
+    const char* e = getenv("CASE_GEMM_TILE_POLICY");
+    g_tile_policy = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  }
+  return g_tile_policy;
+}
+}  // namespace
+
+extern "C" int case_gemm_tile_policy(int32_t policy) {
+  g_tile_policy = policy < 0 ? 0 : (policy > 2 ? 2 : policy);
+  return 0;
 }
 
 extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
@@ -106,6 +135,18 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
               ok(aux_out, d->ld_aux, d->saux1, d->saux2, ept) && ok(bias_col, 4, 0, 0, 4);
   }
   hipStream_t s = (hipStream_t)stream;
+  // interior bf16 problems large enough to fill the chip with 256x256 tiles go to the large-tile kernel
+  if (d->in_dtype == CASE_BF16 && d->batch1 * d->batch2 == 1 && d->M % 256 == 0 && d->N % 256 == 0 && d->K % 64 == 0 &&
+      a.vec_a && a.vec_b && a.vec_c && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
+      (!(epi & CASE_EPI_ATOMIC) || (epi == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32)) && tile_policy() > 0) {
+    const int cus = device_cus();
+    const int64_t t256 = (d->M / 256) * (d->N / 256) * a.split_k;
+    if (tile_policy() == 2 || gemm_t256::prefer(nwg, t256, cus)) {
+      if (d->out_dtype == CASE_BF16) return gemm_t256::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+      if (epi & CASE_EPI_ATOMIC) return gemm_t256::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+      return gemm_t256::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    }
+  }
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return gemm_w4::launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return gemm_w4::launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_F32 && d->out_dtype == CASE_F32) return gemm_w4::launch<float, float>(a, epi, d->a_kmajor, d->b_kmajor, s);

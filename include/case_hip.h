@@ -86,6 +86,12 @@ typedef struct {
 int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
               const float* bias_row, const void* aux, void* aux_out, case_stream_t stream);
 
+/* case_gemm owns two tilings: 128x128 (every shape / dtype / batch) and 256x256 (bf16, M % 256 == N % 256 == 0,
+ * K % 64 == 0, unbatched, 16-byte aligned; accumulators in AGPRs, persistent).  policy: 0 = 128x128 only,
+ * 1 = pick per call by a cost model (default), 2 = 256x256 whenever the call is eligible.  Results of the two tilings
+ * agree to f32 summation order.  Always returns 0; the setting is process-wide (tests and A/B measurements). */
+int case_gemm_tile_policy(int32_t policy);
+
 /* ---------------------------------------------------------------------------------------------
  * K1  embedding gather * sqrt(H) + sinusoid position (+ dropout)
  *   common/TransformerSeqEncoderDecoder.py:21,36  common/PositionalEmbedding.py:44-48  CaSE/Model.py:21,67

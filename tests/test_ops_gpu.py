@@ -354,6 +354,108 @@ def test_gemm_k_tile_counts(dt):
             _close(y, ref, _tol(dt), "gemm K=%d M=%d N=%d" % (K, M, N))
 
 
+class _TilePolicy:
+    """case_gemm_tile_policy for the duration of a block (0 = 128x128 only, 2 = 256x256 whenever eligible)."""
+
+    def __init__(self, policy):
+        self.policy = policy
+
+    def __enter__(self):
+        from case_rg_amd import _abi
+        _abi.call("case_gemm_tile_policy", self.policy)
+
+    def __exit__(self, *exc):
+        from case_rg_amd import _abi
+        _abi.call("case_gemm_tile_policy", 1)
+
+
+def _gemm_both_tilings(fn):
+    with _TilePolicy(0):
+        small = fn()
+    with _TilePolicy(2):
+        large = fn()
+    torch.cuda.synchronize()
+    return small, large
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_large_tile_layouts(layout):
+    """256x256 tiling against the 128x128 tiling and torch: 1..5 K tiles (pipeline prologue / tail), several output tiles."""
+    ops = _ops()
+    dt = torch.bfloat16
+    for (M, N, K) in ((256, 256, 64), (512, 768, 128), (256, 512, 192), (768, 256, 320)):
+        if layout == "nt":      # C = A[M,K] . B[N,K]^T
+            a, b = _rand(M, K, dt=dt, seed=1), _rand(N, K, dt=dt, seed=2, scale=K ** -0.5)
+            ref = a.float() @ b.float().t()
+            fn = lambda: ops.gemm(a, b, torch.empty(M, N, device="cuda", dtype=dt), M, N, K, K, K, N)
+        elif layout == "nn":    # C = A[M,K] . B[K,N]
+            a, b = _rand(M, K, dt=dt, seed=1), _rand(K, N, dt=dt, seed=2, scale=K ** -0.5)
+            ref = a.float() @ b.float()
+            fn = lambda: ops.gemm(a, b, torch.empty(M, N, device="cuda", dtype=dt), M, N, K, K, N, N, b_kmajor=True)
+        else:                   # C = A[K,M]^T . B[K,N]
+            a, b = _rand(K, M, dt=dt, seed=1), _rand(K, N, dt=dt, seed=2, scale=K ** -0.5)
+            ref = a.float().t() @ b.float()
+            fn = lambda: ops.gemm(a, b, torch.empty(M, N, device="cuda", dtype=dt), M, N, K, M, N, N, a_kmajor=True,
+                                  b_kmajor=True)
+        small, large = _gemm_both_tilings(fn)
+        _close(large, ref, 2e-2, "large tile %s M=%d N=%d K=%d" % (layout, M, N, K))
+        _close(large, small.float(), 1e-2, "tilings agree %s M=%d N=%d K=%d" % (layout, M, N, K))
+
+
+def test_gemm_large_tile_epilogues_and_persistence():
+    """Fused epilogues of the 256x256 tiling (bias + GELU with the saved pre-activation, dropout + residual with the same
+    keep mask as the 128x128 tiling, f32 output) and more tiles than CUs (workgroups walk several tiles)."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    dt = torch.bfloat16
+    M, N, K = 512, 512, 128
+    x, w = _rand(M, K, dt=dt, seed=1), _rand(N, K, dt=dt, seed=2, scale=K ** -0.5)
+    bias, res = _rand(N, seed=3), _rand(M, N, dt=dt, seed=4)
+
+    def gelu():
+        y, pre = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+        ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_GELU, bias_col=bias, aux_out=pre, ld_aux=N)
+        return torch.stack([y.float(), pre.float()])
+    small, large = _gemm_both_tilings(gelu)
+    pre_ref = x.float() @ w.float().t() + bias
+    _close(large[1], pre_ref, 2e-2, "large tile pre-activation")
+    _close(large[0], F.gelu(pre_ref), 2e-2, "large tile gelu")
+    _close(large, small, 1e-2, "gelu epilogue: tilings agree")
+
+    def drop_res():
+        y = torch.empty(M, N, device="cuda", dtype=dt)
+        ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_RESIDUAL, bias_col=bias, aux=res, ld_aux=N,
+                 drop=(0.25, 1234, 77))
+        return y.float()
+    small, large = _gemm_both_tilings(drop_res)
+    _close(large, small, 1e-2, "dropout + residual: same keep mask in both tilings")
+    kept = ((large - res.float()).abs() > 1e-6).float().mean().item()
+    assert 0.70 < kept < 0.80, kept
+
+    def f32_out():
+        y = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        return ops.gemm(x, w, y, M, N, K, K, K, N, alpha=0.5)
+    small, large = _gemm_both_tilings(f32_out)
+    _close(large, 0.5 * (x.float() @ w.float().t()), 1e-3, "large tile f32 out")
+
+    # split-K weight gradient (TN, f32 atomics) with uneven splits
+    Kl = 64 * 11
+    g, xx = _rand(Kl, M, dt=dt, seed=5), _rand(Kl, N, dt=dt, seed=6, scale=Kl ** -0.5)
+
+    def dw():
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+        return ops.gemm(g, xx, out, M, N, Kl, M, N, N, a_kmajor=True, b_kmajor=True, split_k=4, epilogue=A.EPI_ATOMIC)
+    small, large = _gemm_both_tilings(dw)
+    _close(large, g.float().t() @ xx.float(), 2e-3, "large tile split-K")
+
+    # 20 x 16 = 320 output tiles on 256 CUs: the persistent loop and the cross-tile prefetch
+    M2, N2, K2 = 5120, 4096, 192
+    a, b = _rand(M2, K2, dt=dt, seed=7), _rand(N2, K2, dt=dt, seed=8, scale=K2 ** -0.5)
+    small, large = _gemm_both_tilings(lambda: ops.gemm(a, b, torch.empty(M2, N2, device="cuda", dtype=dt), M2, N2, K2, K2, K2, N2))
+    _close(large, a.float() @ b.float().t(), 2e-2, "persistent large tile")
+    _close(large, small.float(), 1e-2, "persistent: tilings agree")
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("T", [1, 2])
 def test_additive_scores_decode_rows(dt, T):

@@ -16,7 +16,10 @@ y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     if mode == "nt":
         ops.gemm(x, w, y, M, N, K, K, K, N)
-    else:
-        g = y
-        ops.gemm(g, w, x, M, K, N, N, K, K, b_kmajor=True)
+    elif mode == "nn":
+        ops.gemm(y, w, x, M, K, N, N, K, K, b_kmajor=True)
+    else:  # tn: dW[N, K] = y^T x
+        from case_rg_amd import _abi as A
+        dw = torch.zeros(N, K, device="cuda")
+        ops.gemm(y, x, dw, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, split_k=2, epilogue=A.EPI_ATOMIC)
 torch.cuda.synchronize()
