@@ -131,7 +131,8 @@ def roofline_step(a, trainer, opt, sched, batch):
         e1.record()
         key = "gemm_kernel<%s,%s,%s,%s>" % ("bf16" if A_.dtype == torch.bfloat16 else "f32", "bf16" if C_.dtype == torch.bfloat16 else "f32",
                                             "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
-        records.append((key, 2.0 * M * N * K * kw.get("batch1", 1) * kw.get("batch2", 1), e0, e1))
+        records.append((key, 2.0 * M * N * K * kw.get("batch1", 1) * kw.get("batch2", 1), e0, e1,
+                        (M, N, K, kw.get("batch1", 1) * kw.get("batch2", 1), kw.get("split_k", 1))))
         return out
 
     ops.gemm = timed_gemm
@@ -141,11 +142,22 @@ def roofline_step(a, trainer, opt, sched, batch):
     finally:
         ops.gemm = raw
     fam = {}
-    for key, flops, e0, e1 in records:
+    shapes = {}
+    for key, flops, e0, e1, shape in records:
+        ms = e0.elapsed_time(e1)
         f = fam.setdefault(key, [0.0, 0.0, 0])
         f[0] += flops
-        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[1] += ms * 1e-3
         f[2] += 1
+        sh = shapes.setdefault((key,) + shape, [0.0, 0.0, 0])
+        sh[0] += flops
+        sh[1] += ms
+        sh[2] += 1
+    if os.environ.get("CASE_BENCH_SHAPES"):  # per-shape table for tuning (not part of the JSON line)
+        with open(os.environ["CASE_BENCH_SHAPES"], "w") as fh:
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                fh.write("%-32s M=%-7d N=%-6d K=%-7d batch=%-5d split=%-3d  n=%-4d %8.3f ms  %7.1f TFLOP/s\n"
+                         % (k[0], k[1], k[2], k[3], k[4], k[5], v[2], v[1], v[0] / v[1] / 1e9))
     key, (flops, secs, n) = max(fam.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
     all_flops, all_secs = sum(v[0] for v in fam.values()), sum(v[1] for v in fam.values())

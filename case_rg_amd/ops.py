@@ -108,14 +108,16 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
 
 
 def _split_for(out_rows, out_cols, k_len, elem_bytes):
-    """split-K factor for weight-gradient GEMMs.  512 workgroups are resident at once (256 CUs x 2); pick the smallest
-    split that (a) gives at least 1024 workgroups and (b) wastes < 8 % of the last round of residency, keeping >= 8 K tiles
-    per split."""
+    """split-K factor for GEMMs with a small output and a long reduction (weight gradients, the vocabulary projection's
+    input gradient).  512 workgroups are resident at once (256 CUs x 2); pick the smallest split that (a) gives at least
+    1024 workgroups and (b) wastes < 8 % of the last round of residency.  Splits keep >= 8 K tiles each, or >= 2 when the
+    output has so few tiles that the chip would otherwise sit idle (the decoder's 512 x 512 weight gradients: 16 tiles)."""
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
     k_tiles = max(1, (k_len * elem_bytes + 127) // 128)
+    min_k_tiles = 8 if tiles >= 128 else 2
     best, best_eff = 1, 0.0
     for split in range(1, 65):
-        if split > 1 and k_tiles // split < 8:
+        if split > 1 and k_tiles // split < min_k_tiles:
             break
         wgs = tiles * split
         eff = wgs / (((wgs + 511) // 512) * 512.0)
@@ -150,6 +152,21 @@ def _dropout_raw(x, p, seed, offset):
 # ----------------------------------------------------------------------------------------------
 # Linear:  y = dropout(x W^T + b) + residual
 # ----------------------------------------------------------------------------------------------
+def _input_grad(g, wc, M, K, N):
+    """dX[M, K] = g[M, N] . W[N, K].  A long reduction over few output tiles (the vocabulary projection: N = 30522 onto
+    M x 512) leaves most CUs idle in one pass, so it is split along N into f32 partial sums and cast afterwards."""
+    tiles = ((M + 127) // 128) * ((K + 127) // 128)
+    if g.dtype == torch.bfloat16 and N >= 4096 and tiles < 256:
+        split = _split_for(M, K, N, 2)
+        if split > 1:
+            acc = torch.zeros(M, K, dtype=torch.float32, device=g.device)
+            gemm(g, wc, acc, M, K, N, N, K, K, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC)
+            return cast(acc, g.dtype)
+    dx = torch.empty(M, K, dtype=g.dtype, device=g.device)
+    gemm(g, wc, dx, M, K, N, N, K, K, b_kmajor=True)
+    return dx
+
+
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, p_drop, out_dtype):
@@ -188,9 +205,7 @@ class LinearFn(Function):
             g = _dropout_raw(g, *drop)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
-            gemm(g, wc, dx, M, K, N, N, K, K, b_kmajor=True)
-            dx = dx.view(xshape)
+            dx = _input_grad(g, wc, M, K, N).view(xshape)
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(g, x2, N, K)
         if has_b and ctx.needs_input_grad[2]:

@@ -354,6 +354,22 @@ def test_gemm_k_tile_counts(dt):
             _close(y, ref, _tol(dt), "gemm K=%d M=%d N=%d" % (K, M, N))
 
 
+def test_linear_wide_output_backward_splits_reduction():
+    """Input gradient of a vocabulary-sized projection (N >= 4096, few output tiles) takes the split-K f32 path."""
+    ops = _ops()
+    M, K, N = 200, 128, 4224
+    x = _rand(M, K, dt=torch.bfloat16, seed=1).requires_grad_(True)
+    w = torch.nn.Parameter(_rand(N, K, seed=2, scale=K ** -0.5))
+    y = ops.linear(x, w, None)
+    g = _rand(M, N, dt=torch.bfloat16, seed=3, scale=0.1)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    F.linear(xr, wr).backward(g.float())
+    _close(x.grad, xr.grad, 2e-2, "split-K dX")
+    _close(w.grad, wr.grad, 2e-2, "dW next to split-K dX")
+
+
 class _TilePolicy:
     """case_gemm_tile_policy for the duration of a block (0 = 128x128 only, 2 = 256x256 whenever eligible)."""
 
