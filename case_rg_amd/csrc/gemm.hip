@@ -137,7 +137,7 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
   hipStream_t s = (hipStream_t)stream;
   // interior bf16 problems large enough to fill the chip with 256x256 tiles go to the large-tile kernel
   if (d->in_dtype == CASE_BF16 && d->batch1 * d->batch2 == 1 && d->M % 256 == 0 && d->N % 256 == 0 && d->K % 64 == 0 &&
-      a.vec_a && a.vec_b && a.vec_c && d->lda < (1 << 22) && d->ldb < (1 << 22) &&
+      a.vec_a && a.vec_b && a.vec_c && d->lda < (1 << 22) && d->ldb < (1 << 22) && d->ldc < (1 << 22) && d->ld_aux < (1 << 22) &&
       (!(epi & CASE_EPI_ATOMIC) || (epi == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32)) && tile_policy() > 0) {
     const int cus = device_cus();
     const int64_t t256 = (d->M / 256) * (d->N / 256) * a.split_k;
