@@ -42,7 +42,7 @@ def manual_seed(seed):
 def next_rng(numel):
     """Reserve ``numel`` counters; returns (seed, offset) for one dropout site."""
     off = _state["offset"]
-    _state["offset"] = off + int(numel)
+    _state["offset"] = off + int(numel) + (int(numel) & 1)  # keep offsets even: the kernels hash element pairs
     return _state["seed"], off
 
 

@@ -102,17 +102,43 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // Counter-based RNG: uniform in [0,1) from (seed, 64-bit element index), keyed by element index so forward and backward
-// (and the fused / unfused attention paths) regenerate the same keep mask.  Two rounds of 32-bit multiply-xorshift
-// (murmur3-style finaliser): a 64-bit splitmix costs eight quarter-rate 32-bit multiplies per element, which made the
-// dropout epilogue of the short-K GEMMs as expensive as their MFMA work; this one costs two.
-__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
-  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+// (and the fused / unfused attention paths) regenerate the same keep mask.  One 32-bit hash serves TWO consecutive elements
+// (16 bits each, element index >> 1 is hashed): 32-bit integer multiplies are quarter rate on gfx950 and the two rounds of
+// multiply-xorshift per element were costing the dropout GEMM epilogues as much as a K = 512 main loop.  A keep test
+// `u >= p` therefore resolves p to 1/65536.  rng_uniform() is the per-element definition; rng_uniform2() returns the pair
+// (idx_even, idx_even + 1) from one hash for the vectorised kernels.
+__device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t pair) {
+  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
   uint32_t h = lo ^ ((hi << 16) | (hi >> 16)) ^ (uint32_t)seed;
   h *= 0x9E3779B1u;
   h ^= (h >> 15) ^ (uint32_t)(seed >> 32);
   h *= 0x85EBCA77u;
   h ^= h >> 13;
-  return (float)(h >> 8) * (1.0f / 16777216.0f);
+  return h;
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+  const uint32_t h = rng_hash(seed, idx >> 1);
+  return (float)((idx & 1) ? (h >> 16) : (h & 0xffffu)) * (1.0f / 65536.0f);
+}
+__device__ __forceinline__ void rng_uniform2(uint64_t seed, uint64_t idx_even, float& u0, float& u1) {
+  const uint32_t h = rng_hash(seed, idx_even >> 1);
+  u0 = (float)(h & 0xffffu) * (1.0f / 65536.0f);
+  u1 = (float)(h >> 16) * (1.0f / 65536.0f);
+}
+// keep-or-zero for 8 consecutive elements starting at idx0 (any parity)
+__device__ __forceinline__ void dropout8(float (&x)[8], uint64_t seed, uint64_t idx0, float p, float scale) {
+  if ((idx0 & 1) == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float u0, u1;
+      rng_uniform2(seed, idx0 + e, u0, u1);
+      x[e] = u0 >= p ? x[e] * scale : 0.f;
+      x[e + 1] = u1 >= p ? x[e + 1] * scale : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = rng_uniform(seed, idx0 + e) >= p ? x[e] * scale : 0.f;
+  }
 }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

@@ -100,8 +100,19 @@ __global__ void dropout_vec_kernel(const T* __restrict__ x, T* __restrict__ y, i
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     float v[E];
     Vec16<T>::load(x + i * E, v);
+    const uint64_t idx0 = offset + (uint64_t)(i * E);
+    if ((idx0 & 1) == 0) {  // one hash per element pair
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = rng_uniform(seed, offset + (uint64_t)(i * E + e)) >= p ? v[e] * scale : 0.f;
+      for (int e = 0; e < E; e += 2) {
+        float u0, u1;
+        rng_uniform2(seed, idx0 + e, u0, u1);
+        v[e] = u0 >= p ? v[e] * scale : 0.f;
+        v[e + 1] = u1 >= p ? v[e + 1] * scale : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = rng_uniform(seed, idx0 + e) >= p ? v[e] * scale : 0.f;
+    }
     Vec16<T>::store(y + i * E, v);
   }
 }
