@@ -121,6 +121,7 @@ def build(a, device):
 def roofline_step(a, trainer, opt, sched, batch):
     """One extra training step with a HIP event pair around every GEMM launch (on the launch stream)."""
     from case_rg_amd import ops
+    from case_rg_amd import _abi as abi
     records = []
     raw = ops.gemm
 
@@ -129,8 +130,10 @@ def roofline_step(a, trainer, opt, sched, batch):
         e0.record()
         out = raw(A_, B_, C_, M, N, K, *args, **kw)
         e1.record()
-        key = "gemm_kernel<%s,%s,%s,%s>" % ("bf16" if A_.dtype == torch.bfloat16 else "f32", "bf16" if C_.dtype == torch.bfloat16 else "f32",
-                                            "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
+        tile = abi.lib.case_gemm_last_tile()  # which tiling case_gemm picked for this launch (rocprofv3 names them apart)
+        key = "%s<%s,%s,%s,%s>" % ("gemm256_kernel" if tile == 256 else "gemm_kernel", "bf16" if A_.dtype == torch.bfloat16 else "f32",
+                                   "bf16" if C_.dtype == torch.bfloat16 else "f32",
+                                   "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
         records.append((key, 2.0 * M * N * K * kw.get("batch1", 1) * kw.get("batch2", 1), e0, e1,
                         (M, N, K, kw.get("batch1", 1) * kw.get("batch2", 1), kw.get("split_k", 1))))
         return out

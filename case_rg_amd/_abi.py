@@ -88,6 +88,8 @@ def _load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.case_version.restype = C.c_int
+    lib.case_gemm_last_tile.restype = C.c_int
+    lib.case_gemm_last_tile.argtypes = []
     lib.case_last_error.restype = C.c_char_p
     return lib
 

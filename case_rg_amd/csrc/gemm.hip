@@ -66,6 +66,7 @@ int device_cus() {
 }
 // 0 = 128x128 only, 1 = cost model, 2 = 256x256 whenever eligible; CASE_GEMM_TILE_POLICY presets it (A/B measurements)
 int g_tile_policy = -1;
+int g_last_tile = 0;
 int tile_policy() {
   if (g_tile_policy < 0) {
     const char* e = getenv("CASE_GEMM_TILE_POLICY");
@@ -74,6 +75,8 @@ int tile_policy() {
   return g_tile_policy;
 }
 }  // namespace
+
+extern "C" int case_gemm_last_tile(void) { return g_last_tile; }
 
 extern "C" int case_gemm_tile_policy(int32_t policy) {
   g_tile_policy = policy < 0 ? 0 : (policy > 2 ? 2 : policy);
@@ -142,11 +145,13 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
     const int cus = device_cus();
     const int64_t t256 = (d->M / 256) * (d->N / 256) * a.split_k;
     if (tile_policy() == 2 || gemm_t256::prefer(nwg, t256, cus)) {
+      g_last_tile = 256;
       if (d->out_dtype == CASE_BF16) return gemm_t256::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
       if (epi & CASE_EPI_ATOMIC) return gemm_t256::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
       return gemm_t256::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
     }
   }
+  g_last_tile = 128;
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return gemm_w4::launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return gemm_w4::launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_F32 && d->out_dtype == CASE_F32) return gemm_w4::launch<float, float>(a, epi, d->a_kmajor, d->b_kmajor, s);

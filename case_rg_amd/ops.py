@@ -278,19 +278,22 @@ class FFNFn(Function):
             epi |= A.EPI_RESIDUAL
         gemm(a, w2c, y, M, N, F_, F_, F_, N, epilogue=epi, bias_col=b2, aux=res2, ld_aux=N, drop=drop_o)
         ctx.save_for_backward(x2, w1c, w2c, a, z)
-        ctx.meta = (x.shape, act, drop_i, drop_o, residual is not None)
+        # y = x + FFN(x): the residual gradient can ride in the epilogue of the dX GEMM instead of a separate add
+        ctx.meta = (x.shape, act, drop_i, drop_o, residual is not None, residual is x and N == K)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w1c, w2c, a, z = ctx.saved_tensors
-        xshape, act, drop_i, drop_o, has_res = ctx.meta
+        xshape, act, drop_i, drop_o, has_res, res_is_x = ctx.meta
         M, K = x2.shape
         F_, N = w1c.shape[0], w2c.shape[0]
         g = dy.reshape(M, N)
         if not g.is_contiguous():
             g = g.contiguous()
-        d_res = dy if has_res else None
+        fuse_res = res_is_x and ctx.needs_input_grad[0] and g.dtype == x2.dtype
+        d_res = dy if (has_res and not fuse_res) else None
+        g_res = g  # the incoming gradient before the output dropout mask is applied
         if drop_o is not None:
             g = _dropout_raw(g, *drop_o)
         dw2 = _weight_grad(g, a, N, F_)
@@ -306,7 +309,10 @@ class FFNFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
-            gemm(dz, w1c, dx, M, K, F_, F_, K, K, b_kmajor=True)
+            if fuse_res:
+                gemm(dz, w1c, dx, M, K, F_, F_, K, K, b_kmajor=True, epilogue=A.EPI_RESIDUAL, aux=g_res, ld_aux=N)
+            else:
+                gemm(dz, w1c, dx, M, K, F_, F_, K, K, b_kmajor=True)
             dx = dx.view(xshape)
         return dx, dw1, db1, dw2, db2, None, None, None, d_res
 

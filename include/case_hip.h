@@ -91,6 +91,9 @@ int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, cons
  * 1 = pick per call by a cost model (default), 2 = 256x256 whenever the call is eligible.  Results of the two tilings
  * agree to f32 summation order.  Always returns 0; the setting is process-wide (tests and A/B measurements). */
 int case_gemm_tile_policy(int32_t policy);
+/* Tile edge (128 or 256) of the kernel the most recent case_gemm call of this process launched; 0 before the first call.
+ * Measurement aid: bench.py uses it to attribute each launch to the kernel rocprofv3 will name. */
+int case_gemm_last_tile(void);
 
 /* ---------------------------------------------------------------------------------------------
  * K1  embedding gather * sqrt(H) + sinusoid position (+ dropout)
