@@ -37,7 +37,11 @@ class MultiheadAttention(nn.Module):
     def self_attention(self, x, key_valid=None, causal=False, residual=None, p_res=0.0):
         """x [N, L, E] -> out_proj(attention(x)) (+ dropout, + residual)."""
         E = self.embed_dim
-        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias)
+        if residual is x and torch.is_grad_enabled() and x.requires_grad:
+            # x + out_proj(attention(in_proj(x))): both gradients of x meet in the in-projection's dX GEMM
+            qkv, residual = ops.linear_carry(x, self.in_proj_weight, self.in_proj_bias)
+        else:
+            qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias)
         ctx = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, self.num_heads, self.head_dim, key_valid=key_valid, causal=causal,
                             p_drop=config.drop_p(self.dropout, self.training))
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,

@@ -168,8 +168,12 @@ def _input_grad(g, wc, M, K, N):
 
 
 class LinearFn(Function):
+    """y = dropout(x W^T + b) + residual.  With ``carry`` the input is handed back as a second output: a caller that adds x
+    to something computed from y (x + out_proj(attention(in_proj(x)))) takes its residual from that output, and both
+    gradients of x then arrive here together -- the sum rides in the epilogue of the dX GEMM instead of a separate add."""
+
     @staticmethod
-    def forward(ctx, x, w, b, residual, p_drop, out_dtype):
+    def forward(ctx, x, w, b, residual, p_drop, out_dtype, carry=False):
         K, N = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, K)
         if not x2.is_contiguous():
@@ -189,10 +193,12 @@ class LinearFn(Function):
         gemm(x2, wc, y, M, N, K, K, K, N, epilogue=epi, bias_col=b, aux=res2, ld_aux=N, drop=drop)
         ctx.save_for_backward(x2, wc)
         ctx.meta = (x.shape, b is not None, residual is not None, drop, w.dtype)
+        if carry:
+            return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_carry=None):
         x2, wc = ctx.saved_tensors
         xshape, has_b, has_res, drop, _ = ctx.meta
         M, K = x2.shape
@@ -205,12 +211,21 @@ class LinearFn(Function):
             g = _dropout_raw(g, *drop)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(g, wc, M, K, N).view(xshape)
+            if d_carry is not None and d_carry.dtype == x2.dtype:
+                extra = d_carry.reshape(M, K)
+                extra = extra if extra.is_contiguous() else extra.contiguous()
+                dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+                gemm(g, wc, dx, M, K, N, N, K, K, b_kmajor=True, epilogue=A.EPI_RESIDUAL, aux=extra, ld_aux=K)
+                dx = dx.view(xshape)
+            else:
+                dx = _input_grad(g, wc, M, K, N).view(xshape)
+                if d_carry is not None:
+                    dx = dx + d_carry.to(dx.dtype)
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(g, x2, N, K)
         if has_b and ctx.needs_input_grad[2]:
             db = _colsum(g)
-        return dx, dw, db, d_res, None, None
+        return dx, dw, db, d_res, None, None, None
 
 
 class RowDotFn(Function):
@@ -240,6 +255,11 @@ class RowDotFn(Function):
         db = torch.zeros(1, dtype=torch.float32, device=x2.device) if has_b else None
         A.call("case_rowdot_bwd", _ptr(g), _ptr(x2), _ptr(wv), _ptr(dx), _ptr(dw), _ptr(db), R, C, _code(x2), _stream())
         return (None if dx is None else dx.view(xshape)), dw.view(wshape), db
+
+
+def linear_carry(x, w, b=None):
+    """(x W^T + b, x'): x' is x routed through the op so that a later ``+ x'`` merges its gradient into this op's dX GEMM."""
+    return LinearFn.apply(x, w, b, None, 0.0, None, True)
 
 
 def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None):

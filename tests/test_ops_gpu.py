@@ -354,6 +354,26 @@ def test_gemm_k_tile_counts(dt):
             _close(y, ref, _tol(dt), "gemm K=%d M=%d N=%d" % (K, M, N))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_linear_carry_merges_both_gradients_of_x(dt):
+    """x + f(linear(x)): with linear_carry the residual's gradient is added in the dX GEMM epilogue."""
+    ops = _ops()
+    M, K, N = 130, 64, 192
+    x = _rand(M, K, dt=dt, seed=1).requires_grad_()
+    w, b = _rand(N, K, seed=2, scale=K ** -0.5).requires_grad_(), _rand(N, seed=3).requires_grad_()
+    y, xc = ops.linear_carry(x, w, b)
+    out = y[:, :K] * 0.5 + xc
+    g = _rand(M, K, dt=dt, seed=4)
+    out.backward(g)
+    xr = x.detach().float().requires_grad_()
+    wr, br = w.detach().to(dt).float().requires_grad_(), b.detach().float().requires_grad_()
+    outr = F.linear(xr, wr, br)[:, :K] * 0.5 + xr
+    outr.backward(g.float())
+    _close(out, outr, _tol(dt), "carry out")
+    _close(x.grad, xr.grad, 2 * _tol(dt), "carry dx")
+    _close(w.grad, wr.grad, 2 * _tol(dt), "carry dw")
+
+
 def test_linear_wide_output_backward_splits_reduction():
     """Input gradient of a vocabulary-sized projection (N >= 4096, few output tiles) takes the split-K f32 path."""
     ops = _ops()
