@@ -118,6 +118,22 @@ def build(a, device):
     return trainer, opt, sched, batch
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of ``kernel_key`` from the newest committed PMC summary (profiles/*_pmc_traffic.json, made by
+    tools/pmc_traffic.py from two rocprofv3 --pmc passes of this same command); None when there is none."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            k = json.load(fh)["kernels"].get(kernel_key)
+        return (k["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])) if k else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def roofline_step(a, trainer, opt, sched, batch):
     """One extra training step with a HIP event pair around every GEMM launch (on the launch stream)."""
     from case_rg_amd import ops
@@ -134,8 +150,12 @@ def roofline_step(a, trainer, opt, sched, batch):
         key = "%s<%s,%s,%s,%s>" % ("gemm256_kernel" if tile == 256 else "gemm_kernel", "bf16" if A_.dtype == torch.bfloat16 else "f32",
                                    "bf16" if C_.dtype == torch.bfloat16 else "f32",
                                    "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
-        records.append((key, 2.0 * M * N * K * kw.get("batch1", 1) * kw.get("batch2", 1), e0, e1,
-                        (M, N, K, kw.get("batch1", 1) * kw.get("batch2", 1), kw.get("split_k", 1))))
+        nb = kw.get("batch1", 1) * kw.get("batch2", 1)
+        # algorithmic HBM bytes of the launch: each operand once, C once (read-modify-write counts twice for split-K
+        # accumulation), plus the epilogue's aux operand / saved pre-activation when present
+        nbytes = nb * ((M * K + N * K) * A_.element_size() + M * N * C_.element_size() * (2 if kw.get("split_k", 1) > 1 else 1))
+        nbytes += nb * M * N * A_.element_size() * ((kw.get("aux") is not None) + (kw.get("aux_out") is not None))
+        records.append((key, 2.0 * M * N * K * nb, e0, e1, (M, N, K, nb, kw.get("split_k", 1)), nbytes))
         return out
 
     ops.gemm = timed_gemm
@@ -146,12 +166,13 @@ def roofline_step(a, trainer, opt, sched, batch):
         ops.gemm = raw
     fam = {}
     shapes = {}
-    for key, flops, e0, e1, shape in records:
+    for key, flops, e0, e1, shape, nbytes in records:
         ms = e0.elapsed_time(e1)
-        f = fam.setdefault(key, [0.0, 0.0, 0])
+        f = fam.setdefault(key, [0.0, 0.0, 0, 0.0])
         f[0] += flops
         f[1] += ms * 1e-3
         f[2] += 1
+        f[3] += nbytes
         sh = shapes.setdefault((key,) + shape, [0.0, 0.0, 0])
         sh[0] += flops
         sh[1] += ms
@@ -161,11 +182,13 @@ def roofline_step(a, trainer, opt, sched, batch):
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 fh.write("%-32s M=%-7d N=%-6d K=%-7d batch=%-5d split=%-3d  n=%-4d %8.3f ms  %7.1f TFLOP/s\n"
                          % (k[0], k[1], k[2], k[3], k[4], k[5], v[2], v[1], v[0] / v[1] / 1e9))
-    key, (flops, secs, n) = max(fam.items(), key=lambda kv: kv[1][1])
+    key, (flops, secs, n, alg_bytes) = max(fam.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
+    traffic, traffic_src = pmc_traffic(key)
     all_flops, all_secs = sum(v[0] for v in fam.values()), sum(v[1] for v in fam.values())
     return {"bound": "mfma", "kernel": key, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(alg_bytes / n), "launches": n,
             "avg_launch_ms": round(secs / n * 1e3, 4), "flops_per_launch": flops / n,
             "all_gemm_tflops": round(all_flops / all_secs / 1e12, 1), "all_gemm_ms_per_step": round(all_secs * 1e3, 2),
             "families": {k: {"ms": round(v[1] * 1e3, 2), "tflops": round(v[0] / v[1] / 1e12, 1), "launches": v[2]} for k, v in fam.items()}}

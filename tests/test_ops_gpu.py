@@ -158,6 +158,48 @@ def test_softmax_masks_and_empty_rows():
     _close(ops.masked_softmax(xw.view(1, 3, 3000)), torch.softmax(xw, -1).view(1, 3, 3000), 1e-5, "softmax wide")
 
 
+@pytest.mark.parametrize("C", [40, 384, 640, 1024])
+def test_softmax_bf16_row_in_registers(C):
+    """bf16 rows with C % 8 == 0 and C <= 1024 take the wave-per-row vector kernels: column / row masks, causal, an all-masked
+    row, backward, and the dropout output must drop exactly the elements the scalar kernel (f32 input) drops."""
+    ops = _ops()
+    from case_rg_amd import config
+    O, R = 3, 50
+    x = _rand(O, R, C, dt=torch.bfloat16, seed=1).requires_grad_()
+    cv = torch.ones(O, C, dtype=torch.bool, device=DEV)
+    cv[0, C // 2:] = False
+    cv[2, 3] = False
+    rv = torch.ones(O, R, dtype=torch.bool, device=DEV)
+    rv[1, 40:] = False
+    p = ops.masked_softmax(x, cv, rv, outer=O)
+    xr = x.detach().float().requires_grad_()
+    m = rv[:, :, None] & cv[:, None, :]
+    pr = torch.softmax(xr.masked_fill(~m, float("-inf")), -1).masked_fill(~m, 0.0)
+    _close(p, pr, 1e-2, "vec softmax p")
+    assert (p[1, 40:] == 0).all(), "fully masked rows must be exactly zero"
+    g = _rand(O, R, C, dt=torch.bfloat16, seed=2)
+    p.backward(g)
+    pr.backward(g.float())
+    _close(x.grad, torch.nan_to_num(xr.grad), 2e-2, "vec softmax dx")
+    if C >= R:  # causal: query r sees keys 0..r
+        pc = ops.masked_softmax(x.detach(), None, None, outer=O, causal=True)
+        tri = torch.ones(R, C, dtype=torch.bool, device=DEV).tril()
+        prc = torch.softmax(x.detach().float().masked_fill(~tri, float("-inf")), -1)
+        _close(pc, prc, 1e-2, "vec softmax causal")
+    config.set_dropout(True)
+    try:
+        config.manual_seed(77)
+        yv = ops.masked_softmax(x.detach(), cv, rv, outer=O, p_drop=0.3)
+        config.manual_seed(77)
+        ys = ops.masked_softmax(x.detach().float(), cv, rv, outer=O, p_drop=0.3)  # f32 input: scalar kernel, same counters
+        live = pr.detach() > 1e-4
+        assert ((yv == 0) == (ys == 0))[live].all(), "vector and scalar kernels must drop the same elements"
+        kept = (yv != 0)[live].float().mean().item()
+        assert 0.6 < kept < 0.8, kept
+    finally:
+        config.set_dropout(False)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_additive_scores(dt):
     ops = _ops()
