@@ -158,6 +158,27 @@ def test_softmax_masks_and_empty_rows():
     _close(ops.masked_softmax(xw.view(1, 3, 3000)), torch.softmax(xw, -1).view(1, 3, 3000), 1e-5, "softmax wide")
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H", [64, 1000, 50])
+def test_masked_mean(dt, H):
+    """universal_sentence_embedding: mean over valid positions; H = 64 / 1000 take the vector kernels, 50 (bf16) the scalar one."""
+    ops = _ops()
+    n, L = 5, 37
+    x = _rand(n, L, H, dt=dt, seed=1).requires_grad_()
+    valid = torch.zeros(n, L, dtype=torch.bool, device=DEV)
+    for i, k in enumerate((37, 1, 20, 9, 30)):
+        valid[i, :k] = True
+    y = ops.masked_mean(x, valid)
+    xr = x.detach().float().requires_grad_()
+    yr = (xr * valid[:, :, None]).sum(1) / valid.sum(1, keepdim=True)
+    _close(y, yr, _tol(dt), "masked mean")
+    g = _rand(n, H, dt=dt, seed=2)
+    y.backward(g)
+    yr.backward(g.float())
+    _close(x.grad, xr.grad, _tol(dt), "masked mean dx")
+    assert (x.grad[1, 1:] == 0).all()
+
+
 @pytest.mark.parametrize("C", [40, 384, 640, 1024])
 def test_softmax_bf16_row_in_registers(C):
     """bf16 rows with C % 8 == 0 and C <= 1024 take the wave-per-row vector kernels: column / row masks, causal, an all-masked
