@@ -109,11 +109,25 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
 
 def _split_for(out_rows, out_cols, k_len, elem_bytes):
     """split-K factor for GEMMs with a small output and a long reduction (weight gradients, the vocabulary projection's
-    input gradient).  512 workgroups are resident at once (256 CUs x 2); pick the smallest split that (a) gives at least
-    1024 workgroups and (b) wastes < 8 % of the last round of residency.  Splits keep >= 8 K tiles each, or >= 2 when the
-    output has so few tiles that the chip would otherwise sit idle (the decoder's 512 x 512 weight gradients: 16 tiles)."""
-    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    input gradient).  Outputs that the 256x256 persistent tiling takes (bf16, both extents multiples of 256, K of 64) run one
+    workgroup per CU: pick the split whose tile count best fills whole rounds of 256 (minus a small cost per extra split).  Everything else runs
+    the 128x128 tiling, 512 workgroups resident at once: the smallest split with >= 1024 workgroups and < 8 % of the last
+    round wasted.  Splits keep >= 8 K tiles each, or >= 2 when the output has so few tiles that the chip would otherwise sit
+    idle (the decoder's 512 x 512 weight gradients: 16 tiles)."""
     k_tiles = max(1, (k_len * elem_bytes + 127) // 128)
+    if elem_bytes == 2 and out_rows % 256 == 0 and out_cols % 256 == 0 and k_len % 64 == 0 and k_tiles >= 64:
+        tiles = (out_rows // 256) * (out_cols // 256)
+        best, best_score = 1, -1.0
+        for split in range(1, 65):
+            if split > 1 and k_tiles // split < 8:
+                break
+            wgs = tiles * split
+            eff = wgs / (((wgs + 255) // 256) * 256.0)
+            score = eff - 0.004 * split - (0.5 if wgs < 230 else 0.0)  # every extra split is another pass of f32 atomics over C
+            if score > best_score:
+                best, best_score = split, score
+        return best
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
     min_k_tiles = 8 if tiles >= 128 else 2
     best, best_eff = 1, 0.0
     for split in range(1, 65):
@@ -152,6 +166,8 @@ def _dropout_raw(x, p, seed, offset):
 # ----------------------------------------------------------------------------------------------
 # Linear:  y = dropout(x W^T + b) + residual
 # ----------------------------------------------------------------------------------------------
+
+
 def _input_grad(g, wc, M, K, N):
     """dX[M, K] = g[M, N] . W[N, K].  A long reduction over few output tiles (the vocabulary projection: N = 30522 onto
     M x 512) leaves most CUs idle in one pass, so it is split along N into f32 partial sums and cast afterwards."""
