@@ -125,3 +125,17 @@ def test_bench_flop_model_matches_the_survey():
     assert bench.forward_flops(a) / 1e12 == pytest.approx(20.06, rel=0.03)
     a.enc_layers = 6
     assert bench.forward_flops(a) / 1e12 == pytest.approx(21.53, rel=0.03)
+
+
+def test_split_k_heuristic_fills_whole_rounds():
+    """Weight-gradient split-K: 256x256-eligible outputs fill rounds of 256 persistent workgroups, the rest rounds of 512."""
+    from case_rg_amd import ops
+    k = 122880  # B*P*Lp rows of cfg 2 are the reduction of every weight gradient
+    for rows, cols in ((7680, 2560), (512, 512), (1536, 512), (2560, 2560), (1024, 512)):
+        split = ops._split_for(rows, cols, k, 2)
+        wgs = (rows // 256) * (cols // 256) * split
+        assert wgs / (-(-wgs // 256) * 256.0) >= 0.92, (rows, cols, split)
+        assert (k // 64) // split >= 8
+    assert ops._split_for(512, 512, 1280, 2) == 10          # 16 tiles of 128: two K tiles per split keep 160 workgroups busy
+    assert ops._split_for(30522, 512, 1280, 2) <= 2         # 956 tiles already fill the chip
+    assert ops._split_for(64, 64, 64, 4) == 1               # nothing to split
