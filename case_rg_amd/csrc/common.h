@@ -141,11 +141,32 @@ __device__ __forceinline__ void dropout8(float (&x)[8], uint64_t seed, uint64_t 
   }
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// GELU (erf form, as F.gelu) and its derivative.  Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 on erf): with z = |x| / sqrt 2, t = 1 / (1 + p z), q = (a1 t + ... + a5 t^5) exp(-z^2) the tail
+// 1 - erf(z) IS q, so Phi(-|x|) = q / 2 carries no cancellation, and exp(-z^2) = exp(-x^2 / 2) is also the density the
+// derivative needs.  Two transcendentals (v_rcp, v_exp) + 10 FMAs; libm's erff is ~3x that, and in a GEMM epilogue at one wave
+// per SIMD nothing hides it.
+struct GeluTerms {
+  float cdf, pdf;
+};
+__device__ __forceinline__ GeluTerms gelu_terms(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  const float e = __expf(-z * z);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = 0.5f * p * t * e;  // Phi(-|x|)
+  GeluTerms r;
+  r.cdf = x >= 0.f ? 1.f - q : q;
+  r.pdf = 0.39894228040143268f * e;
+  return r;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_terms(x).cdf; }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const GeluTerms g = gelu_terms(x);
+  return g.cdf + x * g.pdf;
 }
 
 static inline int grid_for(int64_t n, int block, int per_thread = 1, int cap = 256 * 8) {
