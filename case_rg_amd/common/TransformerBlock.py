@@ -5,6 +5,7 @@
     y[pad] = 0                     (:31)
 This block at width 5H (head_dim 5H/8) carries ~73 % of CaSE's forward FLOPs.
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -34,8 +35,12 @@ class TransformerBlock(nn.Module):
         x = input.reshape(B * N, L, E)
         valid = input_mask.reshape(B * N, L)
         p = config.drop_p(0.1, self.training)
-        n1 = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        r = self.self_attn.self_attention(n1, valid, residual=x, p_res=0.1)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # x + MHA(LN(x)): the residual gradient of x is added inside the LayerNorm backward kernel
+            n1, xres = ops.layer_norm_carry(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        else:
+            n1, xres = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), x
+        r = self.self_attn.self_attention(n1, valid, residual=xres, p_res=0.1)
         n2 = ops.layer_norm(r, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         y = ops.ffn(n2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                     self.activation, p_inner=p, p_out=0.0)

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
                                                             const T* __restrict__ x2, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
-                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta,
-                                                            int64_t rows, int64_t cols) {
+                                                            const T* __restrict__ dx_add, float* __restrict__ d_gamma,
+                                                            float* __restrict__ d_beta, int64_t rows, int64_t cols) {
   __shared__ float red[32];
   float acc_g[LN_MAXPT], acc_b[LN_MAXPT];
 #pragma unroll
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
       if (c < cols) {
         const float xh = (Elem<T>::ld(xr + c) + (x2r ? Elem<T>::ld(x2r + c) : 0.f) - mu) * rs;
         const float g = Elem<T>::ld(dyr + c) * gamma[c];
-        Elem<T>::st(dxr + c, rs * (g - m1 - xh * m2));
+        Elem<T>::st(dxr + c, rs * (g - m1 - xh * m2) + (dx_add ? Elem<T>::ld(dx_add + r * cols + c) : 0.f));
       }
     }
   }
@@ -157,8 +157,9 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ x2, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         T* __restrict__ dx, float* __restrict__ d_gamma,
-                                                         float* __restrict__ d_beta, int64_t rows, int64_t cols) {
+                                                         T* __restrict__ dx, const T* __restrict__ dx_add,
+                                                         float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
+                                                         int64_t cols) {
   constexpr int E = Vec16<T>::N;
   extern __shared__ float part[];  // [2][cols] partial d_gamma / d_beta of waves 1..3, added to wave 0's
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -209,6 +210,12 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
         float o[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
+        if (dx_add) {  // a second gradient of the same tensor (its residual use), summed here instead of by a separate pass
+          float w[E];
+          Vec16<T>::load(dx_add + r * cols + c, w);
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] += w[e];
+        }
         Vec16<T>::store(dx + r * cols + c, o);
       }
     }
@@ -280,12 +287,13 @@ void ln_fwd_vec_launch(const void* x, const void* x2, const float* gamma, const 
 
 template <typename T>
 void ln_bwd_vec_launch(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
-                       const float* rstd, void* dx, float* dg, float* db, int64_t rows, int64_t cols, hipStream_t s) {
+                       const float* rstd, void* dx, const void* dx_add, float* dg, float* db, int64_t rows, int64_t cols,
+                       hipStream_t s) {
   constexpr int E = Vec16<T>::N;
   const int nv = (int)((cols + 64 * E - 1) / (64 * E));
   const int grid = grid_for(rows, 4, 16, 256 * 4);  // >= 16 rows per wave: column partials are reduced per workgroup
   const size_t lds = 2 * cols * sizeof(float);
-#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, dg, db, rows, cols)
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
   switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break;
                 case 5: LNB(5); break; case 6: LNB(6); break; case 7: LNB(7); break; default: LNB(8); break; }
 #undef LNB
@@ -534,28 +542,28 @@ extern "C" int case_layernorm_fwd(const void* x, const void* x2, const float* ga
 }
 
 extern "C" int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
-                                  const float* rstd, void* dx, float* d_gamma, float* d_beta, int64_t rows, int64_t cols,
-                                  int32_t dtype, case_stream_t stream) {
+                                  const float* rstd, void* dx, const void* dx_add, float* d_gamma, float* d_beta,
+                                  int64_t rows, int64_t cols, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(dy && x && gamma && mean && rstd && dx && d_gamma && d_beta && rows > 0 && cols > 0,
                "case_layernorm_bwd: bad argument");
   CASE_REQUIRE(cols <= (int64_t)LN_THREADS * LN_MAXPT, "case_layernorm_bwd: cols %lld > %d", (long long)cols,
                LN_THREADS * LN_MAXPT);
   const int grid = grid_for(rows, 1, 8, 256 * 2);  // few workgroups -> few atomics on d_gamma / d_beta
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == CASE_F32 && ln_vec_ok<float>(dy, x, dx, cols) && ln_vec_ok<float>(x2, nullptr, nullptr, cols)) {
-    ln_bwd_vec_launch<float>(dy, x, x2, gamma, mean, rstd, dx, d_gamma, d_beta, rows, cols, s);
+  if (dtype == CASE_F32 && ln_vec_ok<float>(dy, x, dx, cols) && ln_vec_ok<float>(x2, dx_add, nullptr, cols)) {
+    ln_bwd_vec_launch<float>(dy, x, x2, gamma, mean, rstd, dx, dx_add, d_gamma, d_beta, rows, cols, s);
     return case_check_launch("case_layernorm_bwd");
   }
-  if (dtype == CASE_BF16 && ln_vec_ok<bf16_t>(dy, x, dx, cols) && ln_vec_ok<bf16_t>(x2, nullptr, nullptr, cols)) {
-    ln_bwd_vec_launch<bf16_t>(dy, x, x2, gamma, mean, rstd, dx, d_gamma, d_beta, rows, cols, s);
+  if (dtype == CASE_BF16 && ln_vec_ok<bf16_t>(dy, x, dx, cols) && ln_vec_ok<bf16_t>(x2, dx_add, nullptr, cols)) {
+    ln_bwd_vec_launch<bf16_t>(dy, x, x2, gamma, mean, rstd, dx, dx_add, d_gamma, d_beta, rows, cols, s);
     return case_check_launch("case_layernorm_bwd");
   }
   if (dtype == CASE_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(LN_THREADS), 0, s, (const float*)dy, (const float*)x,
-                       (const float*)x2, gamma, mean, rstd, (float*)dx, d_gamma, d_beta, rows, cols);
+                       (const float*)x2, gamma, mean, rstd, (float*)dx, (const float*)dx_add, d_gamma, d_beta, rows, cols);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)x2, gamma, mean, rstd, (bf16_t*)dx, d_gamma, d_beta, rows, cols);
+                       (const bf16_t*)x2, gamma, mean, rstd, (bf16_t*)dx, (const bf16_t*)dx_add, d_gamma, d_beta, rows, cols);
   return case_check_launch("case_layernorm_bwd");
 }
 

@@ -380,8 +380,11 @@ def ffn(x, w1, b1, w2, b2, act, p_inner=0.0, p_out=0.0, residual=None):
 # LayerNorm (optionally of a sum)
 # ----------------------------------------------------------------------------------------------
 class LayerNormFn(Function):
+    """LN(x [+ x2]).  With ``carry`` (x2 must be None) x is handed back as a second output for a residual use
+    (x + f(LN(x))): both gradients of x then arrive here and are summed inside the backward kernel."""
+
     @staticmethod
-    def forward(ctx, x, x2, gamma, beta, eps):
+    def forward(ctx, x, x2, gamma, beta, eps, carry=False):
         C = x.shape[-1]
         xa = x.reshape(-1, C)
         xa = xa if xa.is_contiguous() else xa.contiguous()
@@ -398,24 +401,35 @@ class LayerNormFn(Function):
                _code(xa), _stream())
         ctx.save_for_backward(xa, xb, g, mean, rstd)
         ctx.shape = x.shape
+        if carry:
+            return y.view(x.shape), x.view_as(x)
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_carry=None):
         xa, xb, g, mean, rstd = ctx.saved_tensors
         R, C = xa.shape
         dy2 = dy.reshape(R, C)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        extra = None
+        if d_carry is not None:
+            extra = d_carry.reshape(R, C).to(xa.dtype)
+            extra = extra if extra.is_contiguous() else extra.contiguous()
         dx = torch.empty_like(xa)
         dg, db = _zeros_like_shapes(xa.device, (C,), (C,))
-        A.call("case_layernorm_bwd", _ptr(dy2), _ptr(xa), _ptr(xb), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg),
-               _ptr(db), R, C, _code(xa), _stream())
+        A.call("case_layernorm_bwd", _ptr(dy2), _ptr(xa), _ptr(xb), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(extra),
+               _ptr(dg), _ptr(db), R, C, _code(xa), _stream())
         dx = dx.view(ctx.shape)
-        return dx, (dx if xb is not None else None), dg, db, None
+        return dx, (dx if xb is not None else None), dg, db, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, add=None):
     return LayerNormFn.apply(x, add, gamma, beta, eps)
+
+
+def layer_norm_carry(x, gamma, beta, eps=1e-5):
+    """(LN(x), x'): take a later residual ``+ x`` from x' and its gradient is summed inside the LayerNorm backward kernel."""
+    return LayerNormFn.apply(x, None, gamma, beta, eps, True)
 
 
 # ----------------------------------------------------------------------------------------------

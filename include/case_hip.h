@@ -122,9 +122,11 @@ int case_scale_add_rows(const void* x, const float* pe, void* y, int64_t rows, i
  * ------------------------------------------------------------------------------------------- */
 int case_layernorm_fwd(const void* x, const void* x2, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int64_t rows, int64_t cols, float eps, int32_t dtype, case_stream_t stream);
+/* dx_add (nullable, same layout as dx): a second gradient of the same input -- its residual use, as in
+ * x + MHA(LN(x)) of common/TransformerBlock.py:26-27 -- added to dx in the same pass. */
 int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
-                       const float* rstd, void* dx, float* d_gamma, float* d_beta, int64_t rows, int64_t cols,
-                       int32_t dtype, case_stream_t stream);
+                       const float* rstd, void* dx, const void* dx_add, float* d_gamma, float* d_beta, int64_t rows,
+                       int64_t cols, int32_t dtype, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4/K5/K6 (softmax stage) and the masked softmaxes of K7/K8/K10/K11

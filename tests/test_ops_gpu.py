@@ -159,6 +159,26 @@ def test_softmax_masks_and_empty_rows():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [2560, 70])
+def test_layernorm_carry_sums_both_gradients_of_x(dt, C):
+    """x + f(LN(x)) with layer_norm_carry: the residual gradient is added inside the backward kernel (vector and scalar)."""
+    ops = _ops()
+    R = 37
+    x = _rand(R, C, dt=dt, seed=1).requires_grad_()
+    g, b = (1 + 0.1 * _rand(C, seed=2)).requires_grad_(), _rand(C, seed=3).requires_grad_()
+    y, xc = ops.layer_norm_carry(x, g, b)
+    out = 0.5 * y + xc
+    go = _rand(R, C, dt=dt, seed=4)
+    out.backward(go)
+    xr, gr, br = [t.detach().float().requires_grad_() for t in (x, g, b)]
+    outr = 0.5 * F.layer_norm(xr, (C,), gr, br) + xr
+    outr.backward(go.float())
+    _close(out, outr, _tol(dt), "ln carry out")
+    _close(x.grad, xr.grad, _tol(dt), "ln carry dx")
+    _close(g.grad, gr.grad, 2 * _tol(dt), "ln carry dgamma")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H", [64, 1000, 50])
 def test_masked_mean(dt, H):
     """universal_sentence_embedding: mean over valid positions; H = 64 / 1000 take the vector kernels, 50 (bf16) the scalar one."""
