@@ -21,6 +21,12 @@ __device__ __forceinline__ float tanh_t(float x) {
   }
 }
 
+// Fast path (bf16 operands): with xs = 2 log2(e) (w + u) folded into the operands when they are staged,
+//   r = 1 / (2^xs + 1),  tanh = 1 - 2 r,  1 - tanh^2 = 4 r (1 - r):
+// one add, v_exp, one add, v_rcp per element; the affine parts (1 - 2 r, the factor 4) are applied to the sums.
+constexpr float TANH_PRESCALE = 2.8853900817779268f;  // 2 / ln 2
+__device__ __forceinline__ float half_sigmoid_arg(float xs) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.f); }
+
 constexpr int AJ = 64;   // source positions per workgroup (forward)
 constexpr int AH = 64;   // h chunk staged in LDS
 constexpr int ATW = 8;   // target rows per wave per chunk (4 waves -> 32 per chunk)
@@ -35,28 +41,36 @@ __global__ __launch_bounds__(256) void additive_fwd_kernel(const float* __restri
   const int64_t b = blockIdx.y, j0 = (int64_t)blockIdx.x * AJ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t tc = 0; tc < Tn; tc += 4 * ATW) {
+    constexpr float PS = FAST ? TANH_PRESCALE : 1.f;
     float acc[ATW];
 #pragma unroll
     for (int i = 0; i < ATW; ++i) acc[i] = 0.f;
+    float vsum = 0.f;
     for (int64_t hc = 0; hc < H; hc += AH) {
       __syncthreads();
       for (int e = threadIdx.x; e < AJ * AH; e += 256) {
         const int jj = e / AH, hh = e % AH;
         const int64_t j = j0 + jj, h = hc + hh;
-        U[jj][hh] = (j < S && h < H) ? Elem<T>::ld(uh + (b * S + j) * H + h) : 0.f;
+        U[jj][hh] = (j < S && h < H) ? PS * Elem<T>::ld(uh + (b * S + j) * H + h) : 0.f;
       }
       for (int e = threadIdx.x; e < 4 * ATW * AH; e += 256) {
         const int tt = e / AH, hh = e % AH;
         const int64_t t = tc + tt, h = hc + hh;
-        W[tt][hh] = (t < Tn && h < H) ? wq[(b * Tn + t) * H + h] : 0.f;
+        W[tt][hh] = (t < Tn && h < H) ? PS * wq[(b * Tn + t) * H + h] : 0.f;
       }
       if (threadIdx.x < AH) V[threadIdx.x] = (hc + threadIdx.x < H) ? v[hc + threadIdx.x] : 0.f;
       __syncthreads();
 #pragma unroll 4
       for (int hh = 0; hh < AH; ++hh) {
         const float u = U[lane][hh], vv = V[hh];
+        if constexpr (FAST) {
+          vsum += vv;  // sum_h v_h (1 - 2 r_h) = sum_h v_h - 2 sum_h v_h r_h
 #pragma unroll
-        for (int i = 0; i < ATW; ++i) acc[i] += vv * tanh_t<FAST>(W[wave * ATW + i][hh] + u);
+          for (int i = 0; i < ATW; ++i) acc[i] += vv * half_sigmoid_arg(W[wave * ATW + i][hh] + u);
+        } else {
+#pragma unroll
+          for (int i = 0; i < ATW; ++i) acc[i] += vv * tanh_t<FAST>(W[wave * ATW + i][hh] + u);
+        }
       }
     }
     const int64_t j = j0 + lane;
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(256) void additive_fwd_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < ATW; ++i) {
         const int64_t t = tc + wave * ATW + i;
-        if (t < Tn) s[(b * Tn + t) * S + j] = acc[i];
+        if (t < Tn) s[(b * Tn + t) * S + j] = FAST ? vsum - 2.f * acc[i] : acc[i];
       }
     }
   }
@@ -133,10 +147,10 @@ __global__ __launch_bounds__(256) void additive_bwd_uh_kernel(const float* __res
 #pragma unroll
   for (int jj = 0; jj < BJ; ++jj) {
     const int64_t j = j0 + jj;
-    u[jj] = (h_ok && j < S) ? Elem<T>::ld(uh + (b * S + j) * H + h) : 0.f;
+    u[jj] = (h_ok && j < S) ? (FAST ? TANH_PRESCALE : 1.f) * Elem<T>::ld(uh + (b * S + j) * H + h) : 0.f;
     acc[jj] = 0.f;
   }
-  float dv = 0.f;
+  float dv = 0.f, gsum = 0.f;
   for (int64_t tc = 0; tc < Tn; tc += BTC) {
     __syncthreads();
     for (int e = threadIdx.x; e < BTC * BJ; e += 256) {
@@ -147,24 +161,32 @@ __global__ __launch_bounds__(256) void additive_bwd_uh_kernel(const float* __res
     __syncthreads();
     const int tmax = (int)((Tn - tc) < BTC ? (Tn - tc) : BTC);
     for (int tt = 0; tt < tmax; ++tt) {
-      const float w = h_ok ? wq[(b * Tn + tc + tt) * H + h] : 0.f;
+      const float w = h_ok ? (FAST ? TANH_PRESCALE : 1.f) * wq[(b * Tn + tc + tt) * H + h] : 0.f;
 #pragma unroll
       for (int jj = 0; jj < BJ; ++jj) {
-        const float th = tanh_t<FAST>(w + u[jj]);
         const float g = DS[tt][jj];
-        acc[jj] += g * (1.f - th * th);
-        dv += g * th;
+        if constexpr (FAST) {
+          const float r = half_sigmoid_arg(w + u[jj]);
+          const float gr = g * r;
+          acc[jj] += gr - gr * r;  // g r (1 - r); the factor 4 is applied once at the end
+          dv += gr;                // sum g tanh = sum g - 2 sum g r
+          gsum += g;
+        } else {
+          const float th = tanh_t<FAST>(w + u[jj]);
+          acc[jj] += g * (1.f - th * th);
+          dv += g * th;
+        }
       }
     }
   }
   if (h_ok) {
-    const float vh = v[h];
+    const float vh = FAST ? 4.f * v[h] : v[h];
 #pragma unroll
     for (int jj = 0; jj < BJ; ++jj) {
       const int64_t j = j0 + jj;
       if (j < S) d_uh[(b * S + j) * H + h] = vh * acc[jj];
     }
-    atomicAdd(d_v + h, dv);
+    atomicAdd(d_v + h, FAST ? gsum - 2.f * dv : dv);
   }
 }
 
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __res
 #pragma unroll
   for (int tt = 0; tt < CT; ++tt) {
     const int64_t t = t0 + tt;
-    w[tt] = (h_ok && t < Tn) ? wq[(b * Tn + t) * H + h] : 0.f;
+    w[tt] = (h_ok && t < Tn) ? (FAST ? TANH_PRESCALE : 1.f) * wq[(b * Tn + t) * H + h] : 0.f;
     acc[tt] = 0.f;
   }
   for (int64_t jc = 0; jc < S; jc += CJC) {
@@ -196,16 +218,22 @@ __global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __res
     __syncthreads();
     const int jmax = (int)((S - jc) < CJC ? (S - jc) : CJC);
     for (int jj = 0; jj < jmax; ++jj) {
-      const float u = h_ok ? Elem<T>::ld(uh + (b * S + jc + jj) * H + h) : 0.f;
+      const float u = h_ok ? (FAST ? TANH_PRESCALE : 1.f) * Elem<T>::ld(uh + (b * S + jc + jj) * H + h) : 0.f;
 #pragma unroll
       for (int tt = 0; tt < CT; ++tt) {
-        const float th = tanh_t<FAST>(w[tt] + u);
-        acc[tt] += DS[tt][jj] * (1.f - th * th);
+        if constexpr (FAST) {
+          const float r = half_sigmoid_arg(w[tt] + u);
+          const float gr = DS[tt][jj] * r;
+          acc[tt] += gr - gr * r;
+        } else {
+          const float th = tanh_t<FAST>(w[tt] + u);
+          acc[tt] += DS[tt][jj] * (1.f - th * th);
+        }
       }
     }
   }
   if (h_ok) {
-    const float vh = v[h];
+    const float vh = FAST ? 4.f * v[h] : v[h];
 #pragma unroll
     for (int tt = 0; tt < CT; ++tt) {
       const int64_t t = t0 + tt;
