@@ -158,7 +158,21 @@ struct RowMask {
   __device__ __forceinline__ unsigned long long ballot() const { return __ballot(byte != 0); }
 };
 
-constexpr float RESCALE_THR = 8.f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.69314718055994531f;
+// The softmax runs in the base-2 domain: scores are scaled by scale * log2(e) once, every exponential is a bare v_exp_f32.
+constexpr float RESCALE_THR = 8.f * LOG2E;
+
+// Uniforms of four consecutive counters (the four keys one accumulator register group of a lane covers): two hashes when
+// the first counter is even (element pairs share a hash, common.h), four otherwise.
+__device__ __forceinline__ void rng4(uint64_t seed, uint64_t i0, float (&u)[4]) {
+  if ((i0 & 1) == 0) {
+    rng_uniform2(seed, i0, u[0], u[1]);
+    rng_uniform2(seed, i0 + 2, u[2], u[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = rng_uniform(seed, i0 + k);
+  }
+}
 
 // streamed row index of accumulator register e in a 32-row tile
 __device__ __forceinline__ int acc_row(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
   unsigned long long mask = rm.ballot();
   __syncthreads();
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const float scale2 = a.scale * LOG2E;
   const uint64_t rng_row = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi) * (uint64_t)a.Lk;
 
   for (int t = 0; t < ntiles; ++t) {
@@ -233,12 +248,22 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
       // ---- mask + online softmax (per lane = per query)
       const int key0 = t * TS + kt * 32;
       float mx = -INFINITY;
+      // interior tile: every key valid and (causal) not beyond the wave's first query -> no per-element mask work
+      const bool all_ok = ((mask >> (32 * kt)) & 0xffffffffull) == 0xffffffffull && (!a.causal || key0 + 31 <= q0);
+      if (all_ok) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = key0 + acc_row(e, half);
-        const bool ok = ((mrow >> ((e & 3) + 8 * (e >> 2) + 32 * kt)) & 1ull) && (!a.causal || key <= qi);
-        st[e] = ok ? st[e] * a.scale : -INFINITY;
-        mx = fmaxf(mx, st[e]);
+        for (int e = 0; e < 16; ++e) {
+          st[e] *= scale2;
+          mx = fmaxf(mx, st[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + acc_row(e, half);
+          const bool ok = ((mrow >> ((e & 3) + 8 * (e >> 2) + 32 * kt)) & 1ull) && (!a.causal || key <= qi);
+          st[e] = ok ? st[e] * scale2 : -INFINITY;
+          mx = fmaxf(mx, st[e]);
+        }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // lazy rescale: the running reference max moves only when some query's tile max exceeds it by more than THR;
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
       // exponentiation of this tile and follows the previous tile's P V, so every term is scaled exactly once.
       if (__any(mx > m + RESCALE_THR)) {
         const float m_new = fmaxf(m, mx);
-        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m - m_new);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
         lsum *= alpha;
         m = m_new;
 #pragma unroll
@@ -260,16 +285,18 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
       float ps = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = (m == -INFINITY) ? 0.f : __expf(st[e] - m);
+        const float p = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[e] - m);
         ps += p;
         st[e] = p;
       }
       lsum += ps;
       if (a.drop_p > 0.f) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = key0 + acc_row(e, half);
-          st[e] = rng_uniform(a.seed, rng_row + (uint64_t)key) >= a.drop_p ? st[e] * keep_scale : 0.f;
+        for (int gq = 0; gq < 4; ++gq) {
+          float u[4];
+          rng4(a.seed, rng_row + (uint64_t)(key0 + 8 * gq + 4 * half), u);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) st[4 * gq + k] = u[k] >= a.drop_p ? st[4 * gq + k] * keep_scale : 0.f;
         }
       }
       // ---- O^T += V^T P^T
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
     __syncthreads();
   }
 
-  // ---- finalise: O = O^T / l, LSE = m + log(l)
+  // ---- finalise: O = O^T / l, LSE = ln 2 * m + log(l)  (m is in the base-2 domain)
   lsum += __shfl_xor(lsum, 32, 64);
   const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
   if (qi < a.Lq) {
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
         const uint32_t w1 = f32x2_to_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = make_uint2(w0, w1);
       }
-    if (half == 0) a.lse[((int64_t)n * a.heads + head) * a.Lq + qi] = lsum > 0.f ? m + __logf(lsum) : -INFINITY;
+    if (half == 0) a.lse[((int64_t)n * a.heads + head) * a.Lq + qi] = lsum > 0.f ? m * LN2 + __logf(lsum) : -INFINITY;  // natural log
   }
 }
 
@@ -373,7 +400,8 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(const FaArgs a, const
   load_stationary<D>(qf, Q, a.ldq, q0, a.Lq);
   load_stationary<D>(dof, DO, a.lddo, q0, a.Lq);
   const int64_t stat = ((int64_t)n * a.heads + head) * a.Lq + (qi < a.Lq ? qi : a.Lq - 1);
-  const float lse_q = a.lse[stat], delta_q = a.delta[stat];
+  const float lse2_q = a.lse[stat] * LOG2E, delta_q = a.delta[stat];  // base-2 domain: p = 2^(scale2 s - lse2)
+  const float scale2 = a.scale * LOG2E;
   f32x16 acc[D / 32];
 #pragma unroll
   for (int t = 0; t < D / 32; ++t)
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(const FaArgs a, const
     sk.template store<RS>(smem + KR);
     sk.template store<TR>(smem + KT);
     sv.template store<RS>(smem + VR);
-    const unsigned long long mrow = rm.ballot() >> (4 * half);
+    const unsigned long long mrow_all = rm.ballot(), mrow = mrow_all >> (4 * half);
     __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < TS / 32; ++kt) {
@@ -410,14 +438,30 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(const FaArgs a, const
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + VR, kt * 32, s), dof[s], dp, 0, 0, 0);
       }
       const int key0 = t * TS + kt * 32;
+      if (a.drop_p > 0.f) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = key0 + acc_row(e, half);
-        const bool ok = ((mrow >> ((e & 3) + 8 * (e >> 2) + 32 * kt)) & 1ull) && (!a.causal || key <= qi);
-        const float p = ok ? __expf(st[e] * a.scale - lse_q) : 0.f;
-        float dpe = dp[e];
-        if (a.drop_p > 0.f) dpe = rng_uniform(a.seed, rng_row + (uint64_t)key) >= a.drop_p ? dpe * keep_scale : 0.f;
-        st[e] = p * (dpe - delta_q) * a.scale;  // dS^T
+        for (int gq = 0; gq < 4; ++gq) {
+          float u[4];
+          rng4(a.seed, rng_row + (uint64_t)(key0 + 8 * gq + 4 * half), u);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dp[4 * gq + k] = u[k] >= a.drop_p ? dp[4 * gq + k] * keep_scale : 0.f;
+        }
+      }
+      const bool all_ok = ((mrow_all >> (32 * kt)) & 0xffffffffull) == 0xffffffffull && (!a.causal || key0 + 31 <= q0);
+      if (all_ok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse2_q));
+          st[e] = p * (dp[e] - delta_q) * a.scale;  // dS^T
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + acc_row(e, half);
+          const bool ok = ((mrow >> ((e & 3) + 8 * (e >> 2) + 32 * kt)) & 1ull) && (!a.causal || key <= qi);
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse2_q)) : 0.f;
+          st[e] = p * (dp[e] - delta_q) * a.scale;  // dS^T
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -462,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv_kernel(const FaArgs a, cons
   const int tbegin = a.causal ? (ktile * 128) / TS : 0;  // queries before the first key of this workgroup see none of its keys
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const uint64_t rng_base = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq) * (uint64_t)a.Lk + (uint64_t)ki;
+  const float scale2 = a.scale * LOG2E;
   const float* lse_g = a.lse + ((int64_t)n * a.heads + head) * a.Lq;
   const float* del_g = a.delta + ((int64_t)n * a.heads + head) * a.Lq;
   Stage<D, TS> sq, so;
@@ -474,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv_kernel(const FaArgs a, cons
     float stat = 0.f;
     if (threadIdx.x < 2 * TS) {
       const int r = t * TS + (threadIdx.x % TS);
-      stat = threadIdx.x < TS ? (r < a.Lq ? lse_g[r] : INFINITY) : (r < a.Lq ? del_g[r] : 0.f);  // lse = +inf -> p = 0
+      stat = threadIdx.x < TS ? (r < a.Lq ? lse_g[r] * LOG2E : INFINITY) : (r < a.Lq ? del_g[r] : 0.f);  // lse = +inf -> p = 0
     }
     __syncthreads();
     sq.template store<RS>(smem + QR);
@@ -499,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv_kernel(const FaArgs a, cons
         const int r = qrow0 + acc_row(e, half);
         const int query = t * TS + r;
         const bool ok = key_ok && (!a.causal || ki <= query);
-        const float p = ok ? __expf(st[e] * a.scale - lse_s[r]) : 0.f;
+        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse_s[r])) : 0.f;
         float keep = 1.f;
         if (a.drop_p > 0.f) keep = rng_uniform(a.seed, rng_base + (uint64_t)query * (uint64_t)a.Lk) >= a.drop_p ? keep_scale : 0.f;
         dp[e] = p * (dp[e] * keep - del_s[r]) * a.scale;  // dS

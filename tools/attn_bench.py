@@ -22,7 +22,8 @@ def timeit(fn, iters=5):
 
 
 def main():
-    config.set_dropout(False)
+    p_drop = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0   # python tools/attn_bench.py 0.1 -> with attention dropout
+    config.set_dropout(p_drop > 0.0)
     for d in (320, 64):
         N, h, L = 320, 8, 384
         E = h * d
@@ -30,11 +31,11 @@ def main():
         valid = torch.ones(N, L, dtype=torch.bool, device="cuda")
         g = torch.randn(N, L, E, device="cuda").to(torch.bfloat16)
         fl = 4.0 * N * h * L * L * d
-        t = timeit(lambda: ops.attention(qkv.detach(), qkv.detach(), qkv.detach(), 0, E, 2 * E, h, d, key_valid=valid))
+        t = timeit(lambda: ops.attention(qkv.detach(), qkv.detach(), qkv.detach(), 0, E, 2 * E, h, d, key_valid=valid, p_drop=p_drop))
         print("fwd d=%3d  %7.3f ms  %7.1f TFLOP/s" % (d, t * 1e3, fl / t / 1e12))
 
         def fb():
-            o = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=valid)
+            o = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=valid, p_drop=p_drop)
             o.backward(g)
         t2 = timeit(fb)
         print("fwd+bwd d=%3d  %7.3f ms  (bwd %7.3f ms, %7.1f TFLOP/s on 2.5x fwd flops)" % (d, t2 * 1e3, (t2 - t) * 1e3, 2.5 * fl / (t2 - t) / 1e12))
