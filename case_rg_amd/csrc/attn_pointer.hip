@@ -197,9 +197,15 @@ constexpr int CJC = 64;  // j chunk staged in LDS
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __restrict__ ds, const float* __restrict__ wq,
                                                               const T* __restrict__ uh, const float* __restrict__ v,
-                                                              float* __restrict__ d_wq, int64_t Tn, int64_t S, int64_t H) {
+                                                              float* __restrict__ d_wq, int64_t Tn, int64_t S, int64_t H,
+                                                              int tblocks, int64_t j_per) {
+  // blockIdx.x = (source-position chunk, target-row block): with few target rows (T = 40 -> 5 blocks) one workgroup per
+  // (t block, h block, b) left the chip at one wave per SIMD; the j range is split and partial sums are added atomically
+  // into the pre-zeroed d_wq when there is more than one chunk.
   __shared__ float DS[CT][CJC];
-  const int64_t b = blockIdx.z, t0 = (int64_t)blockIdx.x * CT, h = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  const int64_t b = blockIdx.z, t0 = (int64_t)(blockIdx.x % tblocks) * CT, h = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  const int64_t j_begin = (int64_t)(blockIdx.x / tblocks) * j_per, j_end = (j_begin + j_per < S) ? j_begin + j_per : S;
+  const bool split = j_per < S;
   const bool h_ok = h < H;
   float w[CT], acc[CT];
 #pragma unroll
@@ -208,15 +214,15 @@ __global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __res
     w[tt] = (h_ok && t < Tn) ? (FAST ? TANH_PRESCALE : 1.f) * wq[(b * Tn + t) * H + h] : 0.f;
     acc[tt] = 0.f;
   }
-  for (int64_t jc = 0; jc < S; jc += CJC) {
+  for (int64_t jc = j_begin; jc < j_end; jc += CJC) {
     __syncthreads();
     for (int e = threadIdx.x; e < CT * CJC; e += 256) {
       const int tt = e / CJC, jj = e % CJC;
       const int64_t t = t0 + tt, j = jc + jj;
-      DS[tt][jj] = (t < Tn && j < S) ? ds[(b * Tn + t) * S + j] : 0.f;
+      DS[tt][jj] = (t < Tn && j < j_end) ? ds[(b * Tn + t) * S + j] : 0.f;
     }
     __syncthreads();
-    const int jmax = (int)((S - jc) < CJC ? (S - jc) : CJC);
+    const int jmax = (int)((j_end - jc) < CJC ? (j_end - jc) : CJC);
     for (int jj = 0; jj < jmax; ++jj) {
       const float u = h_ok ? (FAST ? TANH_PRESCALE : 1.f) * Elem<T>::ld(uh + (b * S + jc + jj) * H + h) : 0.f;
 #pragma unroll
@@ -237,7 +243,10 @@ __global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __res
 #pragma unroll
     for (int tt = 0; tt < CT; ++tt) {
       const int64_t t = t0 + tt;
-      if (t < Tn) d_wq[(b * Tn + t) * H + h] = vh * acc[tt];
+      if (t < Tn) {
+        if (split) atomicAdd(d_wq + (b * Tn + t) * H + h, vh * acc[tt]);
+        else d_wq[(b * Tn + t) * H + h] = vh * acc[tt];
+      }
     }
   }
 }
@@ -355,14 +364,23 @@ extern "C" int case_additive_scores_bwd(const float* ds, const float* wq, const 
   CASE_REQUIRE(ds && wq && uh && v && d_wq && d_uh && d_v && B > 0 && T > 0 && S > 0 && H > 0 && B < 65536,
                "case_additive_scores_bwd: bad argument");
   const unsigned hb = (unsigned)((H + 255) / 256);
-  const dim3 g1((unsigned)((S + BJ - 1) / BJ), hb, (unsigned)B), g2((unsigned)((T + CT - 1) / CT), hb, (unsigned)B);
+  const int tblocks = (int)((T + CT - 1) / CT);
+  // split the source positions of sweep 2 until ~2048 workgroups exist (whole CJC chunks per workgroup)
+  const int64_t base_wgs = (int64_t)tblocks * hb * B, j_chunks = (S + CJC - 1) / CJC;
+  int64_t sch = base_wgs >= 2048 ? 1 : (2048 + base_wgs - 1) / base_wgs;
+  if (sch > j_chunks) sch = j_chunks;
+  const int64_t j_per = ((j_chunks + sch - 1) / sch) * CJC;
+  sch = (S + j_per - 1) / j_per;
+  const dim3 g1((unsigned)((S + BJ - 1) / BJ), hb, (unsigned)B), g2((unsigned)(tblocks * sch), hb, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
+  if (sch > 1 && hipMemsetAsync(d_wq, 0, (size_t)(B * T * H) * sizeof(float), st) != hipSuccess)
+    return case_set_error(CASE_E_LAUNCH, "case_additive_scores_bwd: hipMemsetAsync failed");
   if (dtype == CASE_F32) {
     hipLaunchKernelGGL((additive_bwd_uh_kernel<float, false>), g1, dim3(256), 0, st, ds, wq, (const float*)uh, v, d_uh, d_v, T, S, H);
-    hipLaunchKernelGGL((additive_bwd_wq_kernel<float, false>), g2, dim3(256), 0, st, ds, wq, (const float*)uh, v, d_wq, T, S, H);
+    hipLaunchKernelGGL((additive_bwd_wq_kernel<float, false>), g2, dim3(256), 0, st, ds, wq, (const float*)uh, v, d_wq, T, S, H, tblocks, j_per);
   } else {
     hipLaunchKernelGGL((additive_bwd_uh_kernel<bf16_t, true>), g1, dim3(256), 0, st, ds, wq, (const bf16_t*)uh, v, d_uh, d_v, T, S, H);
-    hipLaunchKernelGGL((additive_bwd_wq_kernel<bf16_t, true>), g2, dim3(256), 0, st, ds, wq, (const bf16_t*)uh, v, d_wq, T, S, H);
+    hipLaunchKernelGGL((additive_bwd_wq_kernel<bf16_t, true>), g2, dim3(256), 0, st, ds, wq, (const bf16_t*)uh, v, d_wq, T, S, H, tblocks, j_per);
   }
   return case_check_launch("case_additive_scores_bwd");
 }
