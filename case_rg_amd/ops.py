@@ -487,8 +487,17 @@ def _attn_geometry(src, off, heads, d):
     return dict(t=src, off=off, ld=W, s1=L * W, s2=d, L=L, N=N)
 
 
+# Head sizes with a fused forward but no fused backward (320 = 5H / 8): the fused forward runs at 207 TFLOP/s there (register-
+# bound, one wave per SIMD) against 1.75 ms for QK^T GEMM + vector softmax + PV GEMM, and the unfused forward leaves the
+# probabilities behind for the backward, which otherwise recomputes them.  So they take the unfused path end to end unless
+# this is set (tests of the fused head-dim-320 forward kernel set it).
+FUSE_FORWARD_WITHOUT_BACKWARD = False
+
+
 def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d):
     if q_src.dtype != torch.bfloat16 or not A.lib.case_attention_supported(d):
+        return False
+    if not FUSE_FORWARD_WITHOUT_BACKWARD and not A.lib.case_attention_bwd_supported(d):
         return False
     for t, off in ((q_src, q_off), (k_src, k_off), (v_src, v_off)):
         if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:

@@ -346,6 +346,14 @@ def test_fused_attention_matches_unfused_and_reference(N, h, Lq, Lk, d, causal):
     from case_rg_amd import _abi, config
     ops = _ops()
     assert _abi.lib.case_attention_supported(d)
+    ops.FUSE_FORWARD_WITHOUT_BACKWARD = True  # head_dim 320: keep the fused forward kernel (+ recompute backward) under test
+    try:
+        _fused_attention_case(ops, _abi, config, N, h, Lq, Lk, d, causal)
+    finally:
+        ops.FUSE_FORWARD_WITHOUT_BACKWARD = False
+
+
+def _fused_attention_case(ops, _abi, config, N, h, Lq, Lk, d, causal):
     E, dt = h * d, torch.bfloat16
     valid = torch.ones(N, Lk, dtype=torch.bool, device=DEV)
     valid[1, Lk // 2 + 3:] = False
