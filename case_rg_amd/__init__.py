@@ -33,14 +33,55 @@ def namespace():
         universal_sentence_embedding=Utils.universal_sentence_embedding, topk=Utils.topk)
 
 
+# Hot-path modules that replace the reference's own (north_star / SURVEY 8a); everything else of the caller's ``common`` /
+# ``CaSE`` / ``Masque`` packages (datasets, tokenizers, result writers, baselines' helpers) keeps resolving to the caller's tree.
+DROPIN_MODULES = {
+    "CaSE": ("Model",),
+    "Masque": ("Model",),
+    "common": ("TransformerEncoder", "TransformerDecoder", "TransformerBlock", "PositionalEmbedding", "BilinearAttention",
+               "Interaction", "Highway", "TransformerSeqEncoderDecoder", "CumulativeTrainer", "EMA"),
+}
+# on-path functions of common/Utils.py patched into the caller's module; its other ~40 names stay
+DROPIN_UTILS = ("neginf", "generate_square_subsequent_mask", "init_seed", "new_tensor", "build_map",
+                "universal_sentence_embedding", "topk", "to_sentence")
+
+
 def install_dropin():
-    """Alias this package's ``common`` / ``CaSE`` / ``Masque`` as top-level modules so the reference's launch
-    scripts (``from CaSE.Model import *``, ``from common.CumulativeTrainer import *``) resolve to the HIP path."""
+    """Put the HIP path behind the reference's import paths (CaSE/Run.py:1-11) without touching the rest of its tree.
+
+    With the reference tree importable (its root on ``sys.path``, as ``Run.py`` arranges at :3) only the hot-path
+    submodules are aliased -- ``CaSE.Model``, ``Masque.Model`` and ``common.<DROPIN_MODULES>`` -- and the on-path functions
+    of the caller's ``common.Utils`` are patched; ``CaSE.CaSEDataset``, ``common.Utils.bert_tokenizer``, ``Utils.save_result``
+    ... stay the caller's.  Without a reference tree the three packages are aliased wholesale (stand-alone use)."""
     import importlib
-    import pkgutil
-    for name in ("common", "CaSE", "Masque"):
-        pkg = importlib.import_module(__name__ + "." + name)
-        _sys.modules[name] = pkg
-        for info in pkgutil.iter_modules(pkg.__path__):
-            sub = importlib.import_module("%s.%s.%s" % (__name__, name, info.name))
-            _sys.modules["%s.%s" % (name, info.name)] = sub
+    import importlib.util
+    ours_root = __name__
+    has_tree = {}
+    for pkg, subs in DROPIN_MODULES.items():
+        ours = importlib.import_module("%s.%s" % (ours_root, pkg))
+        cur = _sys.modules.get(pkg)
+        if cur is not None and getattr(cur, "__name__", pkg).startswith(ours_root + "."):
+            del _sys.modules[pkg]  # an earlier stand-alone alias: look the caller's tree up again
+        try:
+            spec = importlib.util.find_spec(pkg)
+        except (ImportError, ValueError):
+            spec = None
+        has_tree[pkg] = spec is not None
+        if spec is None:
+            parent = _sys.modules[pkg] = ours
+            subs = [m.name for m in __import__("pkgutil").iter_modules(ours.__path__)]
+        else:
+            parent = importlib.import_module(pkg)
+        for sub in subs:
+            mod = importlib.import_module("%s.%s.%s" % (ours_root, pkg, sub))
+            _sys.modules["%s.%s" % (pkg, sub)] = mod
+            setattr(parent, sub, mod)
+    if has_tree["common"]:
+        try:
+            ref_utils = importlib.import_module("common.Utils")
+        except ImportError as e:
+            raise ImportError("case_rg_amd.install_dropin: the caller's common.Utils does not import (%s); it is needed for the "
+                              "off-path helpers (tokenizers, data preparation) the launch scripts use" % e) from e
+        our_utils = importlib.import_module(ours_root + ".common.Utils")
+        for name in DROPIN_UTILS:
+            setattr(ref_utils, name, getattr(our_utils, name))

@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: batch schema, deterministic filler, module-attribute graph / state_dict
 schema, helpers restated from common/Utils.py, LR schedule, dropout counter bookkeeping."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -9,6 +10,8 @@ import torch
 import oracle
 from case_rg_amd import config
 from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_synth_batch_follows_the_collate_schema():
@@ -98,22 +101,80 @@ def test_dropout_counter_bookkeeping():
         config.set_compute_dtype(torch.float16)
 
 
-def test_install_dropin_aliases_reference_import_paths():
+def _run_py(code, cwd="/tmp"):
+    import subprocess
     import sys
-    import case_rg_amd
-    saved = {k: sys.modules.get(k) for k in ("common", "CaSE", "Masque")}
-    try:
+    import textwrap
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, cwd=cwd, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_install_dropin_standalone_aliases_whole_packages():
+    """No reference tree on sys.path: ``common`` / ``CaSE`` / ``Masque`` resolve to this package (fresh interpreter)."""
+    out = _run_py("""
+        import sys
+        sys.path.insert(0, %r)
+        import case_rg_amd
         case_rg_amd.install_dropin()
-        from CaSE.Model import CaSE  # noqa: F401  (what CaSE/Run.py does)
-        from common.CumulativeTrainer import CumulativeTrainer, init_params  # noqa: F401
-        from Masque.Model import Masque  # noqa: F401
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                for name in [n for n in sys.modules if n == k or n.startswith(k + ".")]:
-                    del sys.modules[name]
-            else:
-                sys.modules[k] = v
+        from CaSE.Model import CaSE
+        from common.CumulativeTrainer import CumulativeTrainer, init_params
+        from Masque.Model import Masque
+        from common.Utils import build_map, to_sentence
+        print(CaSE.__module__, Masque.__module__, CumulativeTrainer.__module__, build_map.__module__)
+        """ % ROOT)
+    assert out.split() == ["case_rg_amd.CaSE.Model", "case_rg_amd.Masque.Model", "case_rg_amd.common.CumulativeTrainer",
+                           "case_rg_amd.common.Utils"]
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="build container only: needs the reference tree (never on the GPU box)")
+@pytest.mark.parametrize("model", ["CaSE", "Masque"])
+def test_install_dropin_under_the_reference_run_py_imports(model):
+    """the import sequence of CaSE/Run.py:1-11 (Masque/Run.py:1-11) with install_dropin() in front,
+    under the SURVEY 8(c) stubs for the three third-party modules this container lacks.  The reference's own dataset,
+    tokenizer and result-writer names must keep resolving to ITS tree; the model, trainer and on-path helpers to the HIP path."""
+    ds = {"CaSE": "CaSEDataset", "Masque": "MasqueDataset"}[model]
+    out = _run_py("""
+        import sys, types, importlib.machinery, math, torch
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, %r)
+        sys.path.append(%r)                     # Run.py:3  sys.path.append('./') from the reference root
+        for n in ("bcolz", "nltk", "transformers", "transformers.optimization"):
+            m = types.ModuleType(n); m.__spec__ = importlib.machinery.ModuleSpec(n, loader=None); m.__all__ = []
+            sys.modules[n] = m
+        t = sys.modules["transformers"]; t.torch, t.math, t.__all__ = torch, math, ["torch", "math"]
+        import case_rg_amd
+        case_rg_amd.install_dropin()
+        from {M}.{D} import *                   # Run.py:4
+        from torch import optim
+        from common.CumulativeTrainer import *  # :6
+        import torch.backends.cudnn as cudnn
+        import argparse
+        from {M}.Model import *                 # :9
+        from Utils import *                     # :10
+        from transformers.optimization import *
+        import common.TransformerBlock, common.Interaction, common.Constants, common.Generations
+        names = dict(dataset={D}, collate_fn=collate_fn, bert_tokenizer=bert_tokenizer, bert_detokenizer=bert_detokenizer,
+                     model={M}, trainer=CumulativeTrainer, init_params=init_params, save_result=save_result, init_seed=init_seed,
+                     build_map=build_map, block=common.TransformerBlock.TransformerBlock, inter=common.Interaction.Interaction,
+                     greedy=common.Generations.greedy)
+        for k, v in names.items():
+            print(k, v.__module__)
+        print("constants", common.Constants.__file__)
+        """.replace("{M}", model).replace("{D}", ds) % (ROOT, REF))
+    got = dict(line.split() for line in out.strip().splitlines())
+    hip = "case_rg_amd."
+    assert got["dataset"] == "%s.%s" % (model, ds) and got["collate_fn"] == "%s.%s" % (model, ds)
+    assert got["bert_tokenizer"] == "common.Utils" and got["bert_detokenizer"] == "common.Utils"
+    assert got["save_result"] == "Utils" and got["greedy"] == "common.Generations"
+    assert got["constants"].startswith(REF)
+    assert got["model"] == hip + model + ".Model"
+    assert got["trainer"] == hip + "common.CumulativeTrainer" and got["init_params"] == hip + "common.CumulativeTrainer"
+    assert got["init_seed"] == hip + "common.Utils" and got["build_map"] == hip + "common.Utils"
+    assert got["block"] == hip + "common.TransformerBlock" and got["inter"] == hip + "common.Interaction"
 
 
 def test_bench_flop_model_matches_the_survey():
