@@ -137,7 +137,6 @@ def pmc_traffic(kernel_key):
 def roofline_step(a, trainer, opt, sched, batch):
     """One extra training step with a HIP event pair around every GEMM launch (on the launch stream)."""
     from case_rg_amd import ops
-    from case_rg_amd import _abi as abi
     records = []
     raw = ops.gemm
 
@@ -146,7 +145,7 @@ def roofline_step(a, trainer, opt, sched, batch):
         e0.record()
         out = raw(A_, B_, C_, M, N, K, *args, **kw)
         e1.record()
-        tile = abi.lib.case_gemm_last_tile()  # which tiling case_gemm picked for this launch (rocprofv3 names them apart)
+        tile = ops.TILE_TRACE[-1]  # which tiling case_gemm picks for this launch (rocprofv3 names the two kernels apart)
         key = "%s<%s,%s,%s,%s>" % ("gemm256_kernel" if tile == 256 else "gemm_kernel", "bf16" if A_.dtype == torch.bfloat16 else "f32",
                                    "bf16" if C_.dtype == torch.bfloat16 else "f32",
                                    "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
@@ -158,12 +157,12 @@ def roofline_step(a, trainer, opt, sched, batch):
         records.append((key, 2.0 * M * N * K * nb, e0, e1, (M, N, K, nb, kw.get("split_k", 1)), nbytes))
         return out
 
-    ops.gemm = timed_gemm
+    ops.gemm, ops.TILE_TRACE = timed_gemm, []
     try:
         trainer.train_batch(0, dict(batch), "train", opt, sched)
         torch.cuda.synchronize()
     finally:
-        ops.gemm = raw
+        ops.gemm, ops.TILE_TRACE = raw, None
     fam = {}
     shapes = {}
     for key, flops, e0, e1, shape, nbytes in records:

@@ -18,8 +18,8 @@ def namespace():
     """Reference-named classes and helpers in one namespace (what the shared parity cases consume)."""
     from .CaSE.Model import CaSE
     from .Masque.Model import Masque
-    from .common import (BilinearAttention, Highway, Interaction, PositionalEmbedding, TransformerBlock, TransformerDecoder,
-                         TransformerEncoder, TransformerSeqEncoderDecoder, Utils)
+    from .common import (BilinearAttention, CumulativeTrainer, Highway, Interaction, PositionalEmbedding, TransformerBlock,
+                         TransformerDecoder, TransformerEncoder, TransformerSeqEncoderDecoder, Utils, schedule)
     return _types.SimpleNamespace(
         PositionalEmbedding=PositionalEmbedding.PositionalEmbedding,
         TransformerEncoderLayer=TransformerEncoder.TransformerEncoderLayer, TransformerEncoder=TransformerEncoder.TransformerEncoder,
@@ -30,7 +30,8 @@ def namespace():
         TransformerSeqEncoder=TransformerSeqEncoderDecoder.TransformerSeqEncoder,
         TransformerSeqDecoder=TransformerSeqEncoderDecoder.TransformerSeqDecoder, CaSE=CaSE, Masque=Masque,
         generate_square_subsequent_mask=Utils.generate_square_subsequent_mask, build_map=Utils.build_map,
-        universal_sentence_embedding=Utils.universal_sentence_embedding, topk=Utils.topk)
+        universal_sentence_embedding=Utils.universal_sentence_embedding, topk=Utils.topk,
+        CumulativeTrainer=CumulativeTrainer.CumulativeTrainer, lr_schedule=schedule.get_cosine_with_hard_restarts_schedule_with_warmup)
 
 
 # Hot-path modules that replace the reference's own (north_star / SURVEY 8a); everything else of the caller's ``common`` /

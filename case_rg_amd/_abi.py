@@ -21,7 +21,7 @@ i32, i64, u64, f32, ptr = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_
 class GemmDesc(C.Structure):
     _fields_ = [(n, i64) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ld_aux", "batch1", "batch2",
                                    "sa1", "sa2", "sb1", "sb2", "sc1", "sc2", "saux1", "saux2")] + \
-               [(n, i32) for n in ("a_kmajor", "b_kmajor", "in_dtype", "out_dtype", "epilogue", "split_k")] + \
+               [(n, i32) for n in ("a_kmajor", "b_kmajor", "in_dtype", "out_dtype", "epilogue", "split_k", "tile")] + \
                [("alpha", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
 
 
@@ -38,7 +38,6 @@ class AttnDesc(C.Structure):
 # name -> argument types (all return int); mirrors include/case_hip.h one to one
 SIGNATURES = {
     "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
-    "case_gemm_tile_policy": [i32],
     "case_embed_pos_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
     "case_embed_pos_bwd": [ptr, ptr, ptr, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
     "case_scale_add_rows": [ptr, ptr, ptr, i64, i64, i64, f32, i32, ptr],
@@ -88,8 +87,8 @@ def _load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.case_version.restype = C.c_int
-    lib.case_gemm_last_tile.restype = C.c_int
-    lib.case_gemm_last_tile.argtypes = []
+    lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()
+    lib.case_gemm_tile_for.argtypes = [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr]
     lib.case_last_error.restype = C.c_char_p
     return lib
 

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 from torch.utils.data.distributed import DistributedSampler
 
+from .. import ops
 from ..parallel import GradSync
 from .EMA import EMA
 
@@ -29,6 +30,7 @@ def init_params(model, escape=None):
             torch.nn.init.xavier_uniform_(param.data)
     if hasattr(model, 'reset_parameters'):
         model.reset_parameters()
+    ops.invalidate_param_cache()  # writes through .data leave _version alone
 
 
 def _to_device(data):
@@ -88,7 +90,7 @@ class CumulativeTrainer(object):
             if epoch is not None:
                 sampler.set_epoch(epoch)
             return torch.utils.data.DataLoader(dataset, collate_fn=collate_fn, batch_size=batch_size, sampler=sampler, pin_memory=True)
-        return torch.utils.data.DataLoader(dataset, collate_fn=collate_fn, batch_size=batch_size, shuffle=True,
+        return torch.utils.data.DataLoader(dataset, collate_fn=collate_fn, batch_size=batch_size, shuffle=shuffle,
                                            pin_memory=torch.cuda.is_available())
 
     def train_epoch(self, method, train_dataset, train_collate_fn, batch_size, epoch, optimizer, scheduler=None):

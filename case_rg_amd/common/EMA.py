@@ -4,6 +4,8 @@ shadow <- decay * shadow + (1 - decay) * param after every optimizer step; one m
 parameters instead of a Python loop with a clone per tensor."""
 import torch
 
+from .. import ops
+
 
 class EMA():
     def __init__(self, model, decay):
@@ -29,9 +31,11 @@ class EMA():
             assert n in self.shadow
             self.backup[n] = p.data
             p.data = self.shadow[n]
+        ops.invalidate_param_cache()  # p.data swaps do not bump _version: cached bf16 operand copies would go stale
 
     def restore(self):
         for n, p in self._trainable():
             assert n in self.backup
             p.data = self.backup[n]
         self.backup = {}
+        ops.invalidate_param_cache()

@@ -49,8 +49,6 @@ struct Args {
 
 #include "gemm256.inc"
 
-#include <stdlib.h>
-
 namespace {
 constexpr int BM = 128, BN = 128, ROWB = 128;
 
@@ -64,31 +62,18 @@ int device_cus() {
   }
   return cus;
 }
-// 0 = 128x128 only, 1 = cost model, 2 = 256x256 whenever eligible; CASE_GEMM_TILE_POLICY presets it (A/B measurements)
-int g_tile_policy = -1;
-int g_last_tile = 0;
-int tile_policy() {
-  if (g_tile_policy < 0) {
-    const char* e = getenv("CASE_GEMM_TILE_POLICY");
-    g_tile_policy = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
-  }
-  return g_tile_policy;
-}
 }  // namespace
 
-extern "C" int case_gemm_last_tile(void) { return g_last_tile; }
-
-extern "C" int case_gemm_tile_policy(int32_t policy) {
-  g_tile_policy = policy < 0 ? 0 : (policy > 2 ? 2 : policy);
-  return 0;
-}
-
-extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
-                         const float* bias_row, const void* aux, void* aux_out, case_stream_t stream) {
+namespace {
+// Validates the call and fills the kernel arguments; *tile receives the tiling (128 or 256) the call runs on.  Pure: depends on
+// its arguments (and the CU count of the current device) only.
+int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col, const float* bias_row,
+            const void* aux, void* aux_out, Args& a, int* tile) {
   CASE_REQUIRE(d && A && B && C, "case_gemm: null argument");
   CASE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "case_gemm: empty problem M=%lld N=%lld K=%lld", (long long)d->M,
                (long long)d->N, (long long)d->K);
   CASE_REQUIRE(d->batch1 > 0 && d->batch2 > 0, "case_gemm: batch must be positive");
+  CASE_REQUIRE(d->tile == 0 || d->tile == 128 || d->tile == 256, "case_gemm: tile must be 0, 128 or 256");
   const int epi = d->epilogue;
   CASE_REQUIRE(!(epi & CASE_EPI_BIAS_COL) || bias_col, "case_gemm: BIAS_COL without bias_col");
   CASE_REQUIRE(!(epi & CASE_EPI_BIAS_ROW) || bias_row, "case_gemm: BIAS_ROW without bias_row");
@@ -104,9 +89,10 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
                    !(epi & (CASE_EPI_GELU | CASE_EPI_RELU | CASE_EPI_RESIDUAL | CASE_EPI_MUL_DGELU | CASE_EPI_MUL_DRELU |
                             CASE_EPI_DROPOUT)),
                "case_gemm: non-linear epilogue cannot be combined with split-K accumulation");
+  CASE_REQUIRE((d->in_dtype == CASE_BF16 || d->in_dtype == CASE_F32) && (d->out_dtype == CASE_F32 || (d->out_dtype == CASE_BF16 && d->in_dtype == CASE_BF16)),
+               "case_gemm: dtype combination in=%d out=%d", d->in_dtype, d->out_dtype);
   const int esz = d->in_dtype == CASE_BF16 ? 2 : 4;
   const int ept = 16 / esz;
-  Args a;
   a.A = A; a.B = B; a.C = C; a.bias_col = bias_col; a.bias_row = bias_row; a.aux = aux; a.aux_out = aux_out;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ld_aux = d->ld_aux;
   a.batch2 = d->batch2; a.sa1 = d->sa1; a.sa2 = d->sa2; a.sb1 = d->sb1; a.sb2 = d->sb2; a.sc1 = d->sc1;
@@ -137,21 +123,42 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
     a.vec_c = ok(C, d->ldc, d->sc1, d->sc2, eo) && ok(aux, d->ld_aux, d->saux1, d->saux2, ept) &&
               ok(aux_out, d->ld_aux, d->saux1, d->saux2, ept) && ok(bias_col, 4, 0, 0, 4);
   }
-  hipStream_t s = (hipStream_t)stream;
+  *tile = 128;
   // interior bf16 problems large enough to fill the chip with 256x256 tiles go to the large-tile kernel
-  if (d->in_dtype == CASE_BF16 && d->batch1 * d->batch2 == 1 && d->M % 256 == 0 && d->N % 256 == 0 && d->K % 64 == 0 &&
+  if (d->tile != 128 && d->in_dtype == CASE_BF16 && d->batch1 * d->batch2 == 1 && d->M % 256 == 0 && d->N % 256 == 0 && d->K % 64 == 0 &&
       a.vec_a && a.vec_b && a.vec_c && d->lda < (1 << 22) && d->ldb < (1 << 22) && d->ldc < (1 << 22) && d->ld_aux < (1 << 22) &&
-      (!(epi & CASE_EPI_ATOMIC) || (epi == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32)) && tile_policy() > 0) {
-    const int cus = device_cus();
+      (!(epi & CASE_EPI_ATOMIC) || (epi == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32))) {
     const int64_t t256 = (d->M / 256) * (d->N / 256) * a.split_k;
-    if (tile_policy() == 2 || gemm_t256::prefer(nwg, t256, cus)) {
-      g_last_tile = 256;
-      if (d->out_dtype == CASE_BF16) return gemm_t256::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-      if (epi & CASE_EPI_ATOMIC) return gemm_t256::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-      return gemm_t256::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-    }
+    if (d->tile == 256 || gemm_t256::prefer(nwg, t256, device_cus())) *tile = 256;
   }
-  g_last_tile = 128;
+  return 0;
+}
+}  // namespace
+
+extern "C" int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const void* B, const void* C, const float* bias_col,
+                                  const void* aux, const void* aux_out) {
+  Args a;
+  int tile = 0;
+  const float one = 0.f;  // stands in for bias_row: only its presence is validated
+  const int rc = prepare(d, A, B, const_cast<void*>(C), bias_col, (d && (d->epilogue & CASE_EPI_BIAS_ROW)) ? &one : nullptr, aux,
+                         const_cast<void*>(aux_out), a, &tile);
+  return rc ? rc : tile;
+}
+
+extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
+                         const float* bias_row, const void* aux, void* aux_out, case_stream_t stream) {
+  Args a;
+  int tile = 0;
+  const int rc = prepare(d, A, B, C, bias_col, bias_row, aux, aux_out, a, &tile);
+  if (rc) return rc;
+  const int epi = d->epilogue;
+  hipStream_t s = (hipStream_t)stream;
+  if (tile == 256) {
+    const int cus = device_cus();
+    if (d->out_dtype == CASE_BF16) return gemm_t256::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    if (epi & CASE_EPI_ATOMIC) return gemm_t256::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    return gemm_t256::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+  }
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return gemm_w4::launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return gemm_w4::launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_F32 && d->out_dtype == CASE_F32) return gemm_w4::launch<float, float>(a, epi, d->a_kmajor, d->b_kmajor, s);

@@ -49,11 +49,24 @@ def _u8(mask):
 _cast_cache = {}
 
 
+def invalidate_param_cache():
+    """Forget every cached low-precision parameter copy.  ``_version`` does not move when a parameter is rewritten through
+    ``.data`` (``p.data = t``, ``p.data.copy_()``, ``xavier_uniform_(p.data)``, ``dist.broadcast(p.data)``), so the code paths
+    that do that -- ``EMA.apply_shadow`` / ``restore``, ``GradSync.broadcast_parameters``, ``init_params`` -- call this."""
+    _cast_cache.clear()
+
+
+def _evict_dead():
+    for k in [k for k, v in _cast_cache.items() if v[0]() is None]:
+        del _cast_cache[k]
+
+
 def cast_param(p, dtype):
     """fp32 parameter -> operand of the compute dtype.  bf16 copies of nn.Parameters (and of views of them, e.g. the K/V rows
-    of ``in_proj_weight``) are cached until the parameter is updated in place (the optimizer step bumps ``_version``).  The
-    cache is keyed by the owning Parameter object, held through a weak reference: temporaries (``torch.cat`` of weights, test
-    tensors) are never cached -- a freed tensor's address can be handed to a new tensor of the same shape."""
+    of ``in_proj_weight``) are cached until the parameter is updated in place (the optimizer step bumps ``_version``) or its
+    storage is swapped (``p.data = other`` changes ``data_ptr`` / device).  The cache is keyed by the owning Parameter object,
+    held through a weak reference: temporaries (``torch.cat`` of weights, test tensors) are never cached -- a freed tensor's
+    address can be handed to a new tensor of the same shape -- and entries of dead owners are dropped at the next miss."""
     src = p.detach()
     if src.dtype == dtype:
         return src if src.is_contiguous() else src.contiguous()
@@ -62,13 +75,15 @@ def cast_param(p, dtype):
     if owner is None:
         return cast(src, dtype)
     key = (id(owner), src.storage_offset(), tuple(src.shape), tuple(src.stride()), dtype)
+    stamp = (owner._version, owner.data_ptr(), owner.device)
     hit = _cast_cache.get(key)
-    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
+    if hit is not None and hit[0]() is owner and hit[1] == stamp:
         return hit[2]
+    _evict_dead()
     src = src.contiguous()
     out = torch.empty(src.shape, dtype=dtype, device=src.device)
     A.call("case_cast", _ptr(src), _ptr(out), src.numel(), _code(src), _DT[dtype], _stream())
-    _cast_cache[key] = (weakref.ref(owner), owner._version, out)
+    _cast_cache[key] = (weakref.ref(owner), stamp, out)
     return out
 
 
@@ -84,6 +99,13 @@ def cast(x, dtype):
 # ----------------------------------------------------------------------------------------------
 # raw GEMM launcher
 # ----------------------------------------------------------------------------------------------
+# Tiling of the GEMM calls issued from here: 0 = case_gemm's cost model, 128 / 256 = CaseGemmDesc.tile (tests and A/B
+# measurements run the same model under both tilings).  Host-side configuration: the library itself holds no state.
+GEMM_TILE = 0
+# Measurement aid (bench.py): when a list, every launch appends the tile edge case_gemm_tile_for() reports for it.
+TILE_TRACE = None
+
+
 def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          batch1=1, batch2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, epilogue=0, bias_col=None, bias_row=None,
          aux=None, aux_out=None, ld_aux=0, saux=(0, 0), split_k=1, drop=None):
@@ -96,12 +118,22 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
     d.saux1, d.saux2 = saux
     d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
     d.in_dtype, d.out_dtype = _code(a), _code(c)
+    d.tile = GEMM_TILE
     if b.dtype != a.dtype:
         raise TypeError("gemm operands differ in dtype: %s vs %s" % (a.dtype, b.dtype))
+    for name, t in (("aux", aux), ("aux_out", aux_out)):  # the kernels read / write these with the INPUT element size
+        if t is not None and t.dtype != a.dtype:
+            raise TypeError("gemm %s must have the operand dtype %s, got %s" % (name, a.dtype, t.dtype))
+    for name, t in (("bias_col", bias_col), ("bias_row", bias_row)):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("gemm %s must be float32, got %s" % (name, t.dtype))
     if drop is not None and drop[0] > 0.0:
         epilogue |= A.EPI_DROPOUT
         d.drop_p, d.seed, d.offset = drop
     d.epilogue, d.split_k, d.alpha = epilogue, split_k, alpha
+    if TILE_TRACE is not None:
+        TILE_TRACE.append(A.lib.case_gemm_tile_for(d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(aux),
+                                                   _ptr(aux_out)))
     A.call("case_gemm", d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(bias_row), _ptr(aux),
            _ptr(aux_out), _stream())
     return c
@@ -482,22 +514,23 @@ def masked_softmax(x, col_valid=None, row_valid=None, outer=1, causal=False, p_d
 # Multi-head attention core on packed projections (K4 / K5 / K6)
 #   S = alpha Q K^T -> masked softmax (+dropout) -> O = P V, heads addressed in place by batch strides.
 # ----------------------------------------------------------------------------------------------
-def _attn_geometry(src, off, heads, d):
-    N, L, W = src.shape
-    return dict(t=src, off=off, ld=W, s1=L * W, s2=d, L=L, N=N)
+def _src_key(t):
+    """Identity of a projection tensor passed in several roles (packed QKV): two different tensors can share a base address."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
 
 
-# Head sizes with a fused forward but no fused backward (320 = 5H / 8): the fused forward runs at 207 TFLOP/s there (register-
-# bound, one wave per SIMD) against 1.75 ms for QK^T GEMM + vector softmax + PV GEMM, and the unfused forward leaves the
-# probabilities behind for the backward, which otherwise recomputes them.  So they take the unfused path end to end unless
-# this is set (tests of the fused head-dim-320 forward kernel set it).
-FUSE_FORWARD_WITHOUT_BACKWARD = False
+# Which attention path runs:
+#   "auto"    fused kernels for head sizes with a fused forward AND backward; everything else GEMM + softmax + GEMM (the
+#             unfused forward leaves the probabilities behind for the backward, which otherwise recomputes them)
+#   "fused"   the fused forward wherever one is built, even without a fused backward (the backward then recomputes P)
+#   "unfused" never fused (tests run the production-shape fixtures under both)
+ATTENTION_MODE = "auto"
 
 
 def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d):
-    if q_src.dtype != torch.bfloat16 or not A.lib.case_attention_supported(d):
+    if ATTENTION_MODE == "unfused" or q_src.dtype != torch.bfloat16 or not A.lib.case_attention_supported(d):
         return False
-    if not FUSE_FORWARD_WITHOUT_BACKWARD and not A.lib.case_attention_bwd_supported(d):
+    if ATTENTION_MODE != "fused" and not A.lib.case_attention_bwd_supported(d):
         return False
     for t, off in ((q_src, q_off), (k_src, k_off), (v_src, v_off)):
         if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:
@@ -549,9 +582,9 @@ class AttentionFn(Function):
         """One gradient buffer per distinct source tensor (packed projections share one)."""
         bufs = {}
         for src in (q_src, k_src, v_src):
-            key = src.data_ptr()
+            key = _src_key(src)
             if key not in bufs:
-                covered = sum(E for t in (q_src, k_src, v_src) if t.data_ptr() == key)
+                covered = sum(E for t in (q_src, k_src, v_src) if _src_key(t) == key)
                 bufs[key] = torch.empty_like(src) if covered == src.shape[2] else torch.zeros_like(src)
         return bufs
 
@@ -563,14 +596,14 @@ class AttentionFn(Function):
         Lk = k_src.shape[1]
         dO = dO if dO.is_contiguous() else dO.contiguous()
         bufs = AttentionFn._grad_buffers(q_src, k_src, v_src, heads * d)
-        gq, gk, gv = bufs[q_src.data_ptr()], bufs[k_src.data_ptr()], bufs[v_src.data_ptr()]
+        gq, gk, gv = bufs[_src_key(q_src)], bufs[_src_key(k_src)], bufs[_src_key(v_src)]
         delta = torch.empty(N, heads, Lq, dtype=torch.float32, device=dO.device)
         ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)
         A.call("case_attention_bwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O), _ptr(lse),
                _ptr(dO), _ptr(delta), _ptr(gq, q_off), _ptr(gk, k_off), _ptr(gv, v_off), _stream())
         out, seen = [], set()
         for src in (q_src, k_src, v_src):
-            key = src.data_ptr()
+            key = _src_key(src)
             out.append(None if key in seen else bufs[key])
             seen.add(key)
         return (out[0], out[1], out[2]) + (None,) * 8
@@ -611,9 +644,9 @@ class AttentionFn(Function):
         bufs = {}
 
         def grad_of(src):
-            key = src.data_ptr()
+            key = _src_key(src)
             if key not in bufs:
-                covered = sum(E for s in (q_src, k_src, v_src) if s.data_ptr() == key)
+                covered = sum(E for s in (q_src, k_src, v_src) if _src_key(s) == key)
                 bufs[key] = (torch.empty_like(src) if covered == src.shape[2] else torch.zeros_like(src))
             return bufs[key]
 
@@ -634,7 +667,7 @@ class AttentionFn(Function):
              batch2=heads, sa=pstr, sb=(Lq * Wq, d), sc=(Lk * Wk, d), alpha=alpha)
         out, seen = [], set()
         for src in (q_src, k_src, v_src):
-            key = src.data_ptr()
+            key = _src_key(src)
             out.append(None if key in seen else bufs[key])
             seen.add(key)
         return (out[0], out[1], out[2]) + (None,) * 8

@@ -22,6 +22,7 @@ class GradSync:
         self.buckets = []  # [flat buffer, [(param, offset, numel)], pending count, work handle]
         self._slot = {}
         self._armed = False
+        self._next = 0  # index of the next bucket to launch (in-order collectives)
         self.active = dist.is_initialized() and (self.world > 1 or force)
         if not self.active:
             return
@@ -43,15 +44,18 @@ class GradSync:
         p0 = items[0][0]
         flat = torch.zeros(numel, dtype=torch.float32, device=p0.device)
         idx = len(self.buckets)
-        self.buckets.append({"flat": flat, "items": items, "pending": len(items), "work": None})
+        views = [flat[off:off + n].view_as(p) for p, off, n in items]
+        self.buckets.append({"flat": flat, "items": items, "views": views, "pending": len(items), "work": None})
         for p, _, _ in items:
             self._slot[id(p)] = idx
 
     def broadcast_parameters(self, model):
         """Rank 0's parameters and buffers become everyone's (what DDP does at wrap time)."""
+        from . import ops
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
+        ops.invalidate_param_cache()  # the broadcast writes through .data: cached bf16 operand copies are stale
 
     def no_sync(self, flag=True):
         """Gradient accumulation micro-steps: skip the all-reduce (the reference does not)."""
@@ -62,29 +66,43 @@ class GradSync:
             return
         b = self.buckets[self._slot[id(p)]]
         b["pending"] -= 1
-        if b["pending"] == 0:
+        self._launch_ready()
+
+    def _launch_ready(self, flush=False):
+        """Launch buckets strictly in index order -- bucket k only after 0..k-1 -- so every rank issues the same sequence of
+        collectives whatever order its hooks fired in (a parameter that is unused on one rank delays its bucket, and the ones
+        behind it, to ``finish()`` on that rank only; the sequence stays the same)."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b["pending"] > 0 and not flush:
+                return
             self._launch(b)
+            self._next += 1
 
     def _launch(self, b):
-        flat = b["flat"]
-        for p, off, n in b["items"]:
-            flat[off:off + n].copy_(p.grad.reshape(-1)) if p.grad is not None else flat[off:off + n].zero_()
-        b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        """Gather the bucket's gradients into its flat buffer (one multi-tensor copy; gradients that already ARE the bucket
+        views, e.g. after an accumulation micro-step, need none) and start the asynchronous all-reduce."""
+        src, dst = [], []
+        for (p, off, n), view in zip(b["items"], b["views"]):
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                src.append(p.grad)
+                dst.append(view)
+        if src:
+            torch._foreach_copy_(dst, src)
+        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        """Wait for every bucket, average, write the reduced gradients back.  Buckets whose hooks did not all fire
-        (parameters unused this step) are reduced here with zeros for the missing gradients."""
+        """Flush the buckets whose hooks did not all fire (zeros stand in for the missing gradients), wait, average, and make
+        every ``param.grad`` a VIEW of its bucket: the optimizer reads the reduced gradients in place, nothing is copied back."""
         if not self.active or not self._armed:
             return
-        for b in self.buckets:
-            if b["work"] is None:
-                self._launch(b)
+        self._launch_ready(flush=True)
         for b in self.buckets:
             b["work"].wait()
-            flat = b["flat"].div_(self.world)
-            for p, off, n in b["items"]:
-                if p.grad is None:
-                    p.grad = flat[off:off + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
+            b["flat"].div_(self.world)
+            for (p, _, _), view in zip(b["items"], b["views"]):
+                p.grad = view
             b["work"], b["pending"] = None, len(b["items"])
+        self._next = 0

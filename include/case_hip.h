@@ -78,6 +78,8 @@ typedef struct {
   int32_t out_dtype; /* dtype of C */
   int32_t epilogue;  /* CASE_EPI_* mask */
   int32_t split_k;   /* >= 1 */
+  int32_t tile;      /* 0 = pick the tiling per call (cost model); 128 = the 128x128 tiling; 256 = the 256x256 persistent tiling
+                        whenever the call is eligible for it (otherwise 128x128) */
   float alpha;
   float drop_p;
   uint64_t seed, offset;
@@ -87,13 +89,12 @@ int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, cons
               const float* bias_row, const void* aux, void* aux_out, case_stream_t stream);
 
 /* case_gemm owns two tilings: 128x128 (every shape / dtype / batch) and 256x256 (bf16, M % 256 == N % 256 == 0,
- * K % 64 == 0, unbatched, 16-byte aligned; accumulators in AGPRs, persistent).  policy: 0 = 128x128 only,
- * 1 = pick per call by a cost model (default), 2 = 256x256 whenever the call is eligible.  Results of the two tilings
- * agree to f32 summation order.  Always returns 0; the setting is process-wide (tests and A/B measurements). */
-int case_gemm_tile_policy(int32_t policy);
-/* Tile edge (128 or 256) of the kernel the most recent case_gemm call of this process launched; 0 before the first call.
- * Measurement aid: bench.py uses it to attribute each launch to the kernel rocprofv3 will name. */
-int case_gemm_last_tile(void);
+ * K % 64 == 0, unbatched, 16-byte aligned; accumulators in AGPRs, persistent).  CaseGemmDesc.tile selects per call; results
+ * of the two tilings agree to f32 summation order.  case_gemm_tile_for() returns the tile edge (128 or 256) case_gemm would
+ * launch for exactly these arguments (or a negative CASE_E_* code): a pure function of its arguments, no launch, no state --
+ * bench.py uses it to attribute each launch to the kernel name rocprofv3 reports. */
+int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const void* B, const void* C, const float* bias_col,
+                       const void* aux, const void* aux_out);
 
 /* ---------------------------------------------------------------------------------------------
  * K1  embedding gather * sqrt(H) + sinusoid position (+ dropout)

@@ -22,6 +22,20 @@ def _rand(seed, *shape, scale=1.0):
     return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
 
 
+def _strided(t, n=64):
+    """n samples spread over the whole tensor (the first rows of an embedding / vocabulary matrix are special tokens that never
+    receive a gradient)."""
+    flat = t.detach().reshape(-1)
+    return flat[::max(1, flat.numel() // n)][:n].clone()
+
+
+def _sample2d(t, rows=64, cols=128):
+    """[rows, cols] strided sample of a tensor viewed as a matrix over its last dim (large outputs / gradients are stored as
+    samples; the comparison is still element-wise on what is stored)."""
+    m = t.detach().reshape(-1, t.size(-1))
+    return m[::max(1, m.size(0) // rows)][:rows, ::max(1, m.size(1) // cols)][:, :cols].clone()
+
+
 def _valid(seed, rows, length, min_len=2):
     """[rows, length] bool validity with ragged tails (True = token)."""
     rng = np.random.RandomState(seed)
@@ -230,7 +244,7 @@ def _record_batch(b):
     return {"in_" + k: v for k, v in b.items()}
 
 
-def _model_grads(m, losses, names):
+def _model_grads(m, losses, names, strided=False):
     params = dict(m.named_parameters())
     total = sum(l.mean() for l in losses)
     gs = torch.autograd.grad(total, [params[n] for n in names], allow_unused=True)
@@ -238,7 +252,7 @@ def _model_grads(m, losses, names):
     for n, g in zip(names, gs):
         g = torch.zeros_like(params[n]) if g is None else g
         out["gnorm_" + n] = g.norm().reshape(1)
-        out["gslice_" + n] = g.reshape(-1)[:64].clone()
+        out["gslice_" + n] = _strided(g, 256) if strided else g.reshape(-1)[:64].clone()
     return out
 
 
@@ -341,6 +355,87 @@ def case_masque_test(ns, dev):
 
 
 # ---------------------------------------------------------------------------------------------
+# trainer loop (SURVEY a15 / cfg 1 plumbing): CumulativeTrainer.train_epoch with gradient accumulation, an odd number of
+# batches (end-of-epoch flush of a partial group: optimizer step WITHOUT clip / EMA, reference :122-126), clip-norm 1,
+# Adam, LR schedule, EMA; then predict().  The reference's loop, the oracle model under this package's loop and the HIP
+# model under this package's loop must produce the same loss trajectory, weights, EMA shadow and rank scores.
+# ---------------------------------------------------------------------------------------------
+class _ListDataset(torch.utils.data.Dataset):
+    def __init__(self, batch):
+        n = batch["id"].size(0)
+        self.items = [{k: v[i] for k, v in batch.items()} for i in range(n)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _collate(samples):
+    return {k: torch.stack([s[k] for s in samples]) for k in samples[0]}
+
+
+class _unshuffled_loader:
+    """Both trainers build ``torch.utils.data.DataLoader(..., shuffle=True)`` on one process (reference :95); the fixture must
+    not depend on torch's sampler RNG, so the loader is forced to dataset order while a trainer case runs (harness-side, like
+    the dropout patch)."""
+
+    def __enter__(self):
+        self.orig = torch.utils.data.DataLoader
+        orig = self.orig
+
+        class Loader(orig):
+            def __init__(self, dataset, *a, **kw):
+                kw["shuffle"], kw["pin_memory"] = False, False
+                kw.pop("sampler", None)
+                super().__init__(dataset, *a, **kw)
+
+        torch.utils.data.DataLoader = Loader
+
+    def __exit__(self, *exc):
+        torch.utils.data.DataLoader = self.orig
+
+
+TRAINER_NAMES = ["query_encoder.embedding.0.weight", "passage_selection.passage_blocks.0.linear1.weight",
+                 "span_extraction.scorer.weight", "response_generation.decoder.gen.2.weight",
+                 "response_generation.decoder.decs.1.layers.0.multihead_attn.out_proj.weight"]
+
+
+def case_trainer_traj(ns, dev):
+    m = _case_model(ns, dev, 201)
+    data = synth_batch(10, 3, 12, 8, 6, V, seed=202, model="case")
+    train_set = _ListDataset(data)
+    test_set = _ListDataset(synth_batch(4, 3, 12, 8, 6, V, seed=203, model="case"))
+    trainer = ns.CumulativeTrainer(m, None, None, None, 1, accumulation_steps=2)
+    opt = torch.optim.Adam(trainer.model.parameters(), lr=2.5e-3)
+    sched = ns.lr_schedule(opt, 2, 6)
+    losses = []
+    step = trainer.train_batch
+
+    def recording(*a, **kw):
+        losses.append(step(*a, **kw))
+        return losses[-1]
+
+    trainer.train_batch = recording
+    with _unshuffled_loader():
+        trainer.train_epoch("train", train_set, _collate, 2, 0, opt, sched)   # 5 batches: 2 full groups + a flushed half group
+        preds = trainer.predict("test", test_set, _collate, 2)
+    params = dict(trainer.model.named_parameters())
+    rec = {"in_" + k: v for k, v in data.items()}
+    rec["losses"] = torch.tensor(losses, dtype=torch.float32)
+    rec["lr"] = torch.tensor(sched.get_last_lr(), dtype=torch.float32)
+    for n in TRAINER_NAMES:
+        rec["w_norm_" + n] = params[n].detach().norm().reshape(1)
+        rec["w_slice_" + n] = _strided(params[n])
+        rec["ema_slice_" + n] = _strided(trainer.ema.shadow[n])
+    rec["rank"] = torch.cat([out["rank"] for _, out in preds])
+    rec["pred_ids"] = torch.cat([d["id"] for d, _ in preds])
+    rec["answer_shape"] = torch.tensor(list(torch.cat([out["answer"] for _, out in preds]).shape))
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------
 # production-tile shapes (head_dim 64 and 320, L = 384); outputs are stored as strided samples
 # ---------------------------------------------------------------------------------------------
 def _sample_rows(t, step=16):
@@ -368,5 +463,97 @@ def case_prod_block_5h(ns, dev):
     return {"in_valid": valid, "y_rows": _sample_rows(y)}
 
 
+# ---------------------------------------------------------------------------------------------
+# model level at PRODUCTION tile shapes (BASELINE cfg 2 geometry per passage: H = 512, 8 heads -> head_dim 64 and 320,
+# Lp = 384, Lq = 64, T = 40, V = 30522; B = 1, P = 2 so the reference's [B P, Lp, Lq, 3H] temporary stays ~300 MB).
+# These are the shapes at which the bf16 256x256 GEMM tiling, the fused attention kernels and the vector softmax are
+# eligible, so the kernels bench.py times run inside a test whose expected values came from the reference.
+# ---------------------------------------------------------------------------------------------
+PROD_V = 30522
+
+
+def _prod_batch(dev, seed, model):
+    b = synth_batch(1, 2, 384, 64, 40, PROD_V, seed=seed, model=model, filler_passage=False)
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def _prod_model(ns, dev, seed, model):
+    v2i, i2v = make_vocab(PROD_V)
+    m = ns.CaSE(4, 40, i2v, v2i, 512) if model == "case" else ns.Masque(40, i2v, v2i, 512)
+    return _mod(m, seed, dev)
+
+
+def _prod_record(b):
+    return {"in_" + k: v for k, v in b.items() if k in ("query", "passage", "response", "passage_label")}
+
+
+def case_prod_case_train(ns, dev):
+    m = _prod_model(ns, dev, 211, "case")
+    b = _prod_batch(dev, 212, "case")
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_se": losses[1].reshape(1), "loss_rg": losses[2].reshape(1)})
+    rec.update(_model_grads(m, losses, CASE_GRAD_NAMES, strided=True))
+    return rec
+
+
+def case_prod_masque_train(ns, dev):
+    m = _prod_model(ns, dev, 221, "masque")
+    b = _prod_batch(dev, 222, "masque")
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_rg": losses[1].reshape(1)})
+    rec.update(_model_grads(m, losses, MASQUE_GRAD_NAMES, strided=True))
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE cfg 5 geometry (d_model 768 -> head_dim 96 and 480, Lp = 512, decoder memory S = 40 x 512 = 20 480)
+# ---------------------------------------------------------------------------------------------
+def _cfg5_block(ns, dev, seed, width_in):
+    m = _mod(ns.TransformerBlock(8, width_in, 768), seed, dev)
+    x = _rand(seed + 1, 1, 2, 512, width_in).to(dev).requires_grad_()
+    valid = _valid(seed + 2, 2, 512, min_len=256).reshape(1, 2, 512).clone()
+    valid[0, 1, 300:] = False
+    valid = valid.to(dev)
+    y = m(x, valid)
+    out = {"in_valid": valid, "y_rows": _sample2d(y, 128, 256)}
+    g = _grads(_probe([y]), [("x", x), ("in_proj_weight", m.self_attn.in_proj_weight), ("out_proj_weight", m.self_attn.out_proj.weight),
+                             ("norm1_weight", m.norm1.weight), ("linear1_weight", m.linear1.weight)])
+    out.update({k: (_sample2d(v) if v.dim() > 1 else v) for k, v in g.items()})
+    return out
+
+
+def case_cfg5_block_5h(ns, dev):
+    return _cfg5_block(ns, dev, 231, 5 * 768)
+
+
+def case_cfg5_block_h(ns, dev):
+    return _cfg5_block(ns, dev, 241, 768)
+
+
+def case_cfg5_dec_layer_long_memory(ns, dev):
+    """One decoder layer, 40 target positions against the full cfg 5 memory (S = 20 480 keys, ragged tail masked):
+    the long-memory cross-attention (common/TransformerDecoder.py:81-82) at head_dim 96."""
+    m = _mod(ns.TransformerDecoderLayer(768, 8, dim_feedforward=768, dropout=0.1, activation="gelu"), 251, dev)
+    T, S = 40, 20480
+    tgt = _rand(252, T, 1, 768).to(dev).requires_grad_()
+    mem = _rand(253, S, 1, 768).to(dev).requires_grad_()
+    tpad = torch.zeros(1, T, dtype=torch.bool)
+    tpad[0, 33:] = True
+    mpad = torch.zeros(1, S, dtype=torch.bool)
+    mpad[0, 19000:] = True
+    mpad[0, 5000:5100] = True
+    tpad, mpad = tpad.to(dev), mpad.to(dev)
+    causal = ns.generate_square_subsequent_mask(T).to(dev)
+    y, _, _ = m(tgt, mem, tgt_mask=causal, tgt_key_padding_mask=tpad, memory_key_padding_mask=mpad)
+    out = {"in_tpad": tpad, "in_mpad": mpad, "y": y.detach()}
+    g = _grads(_probe([y]), [("tgt", tgt), ("mem", mem), ("cross_in_proj_weight", m.multihead_attn.in_proj_weight),
+                             ("cross_out_proj_bias", m.multihead_attn.out_proj.bias), ("norm2_weight", m.norm2.weight)])
+    out.update({k: (_sample2d(v, 128, 128) if v.numel() > 65536 else v) for k, v in g.items()})
+    return out
+
+
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
+PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory")

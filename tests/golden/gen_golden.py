@@ -47,6 +47,7 @@ def reference_namespace():
     import common.TransformerDecoder as td
     import common.TransformerEncoder as te
     import common.TransformerSeqEncoderDecoder as sed
+    import common.CumulativeTrainer as trainer
     import common.Utils as utils
 
     ns = types.SimpleNamespace(
@@ -57,8 +58,16 @@ def reference_namespace():
         Highway=hw.Highway, TransformerSeqEncoder=sed.TransformerSeqEncoder, TransformerSeqDecoder=sed.TransformerSeqDecoder,
         CaSE=case_model.CaSE, Masque=masque_model.Masque,
         generate_square_subsequent_mask=utils.generate_square_subsequent_mask, build_map=utils.build_map,
-        universal_sentence_embedding=utils.universal_sentence_embedding, topk=utils.topk)
+        universal_sentence_embedding=utils.universal_sentence_embedding, topk=utils.topk,
+        CumulativeTrainer=trainer.CumulativeTrainer, lr_schedule=_lr_schedule())
     return ns
+
+
+def _lr_schedule():
+    """The reference takes its schedule from transformers==2.1.1 (CaSE/Run.py:28), stubbed here: the trainer fixture runs the
+    reference's loop with this package's restatement of that schedule (schedule parity is unpinned)."""
+    from case_rg_amd.common.schedule import get_cosine_with_hard_restarts_schedule_with_warmup
+    return get_cosine_with_hard_restarts_schedule_with_warmup
 
 
 def to_numpy(rec):

@@ -47,3 +47,26 @@ def check_case(name, rec, rtol, atol, grad_rtol=None, grad_atol=None, skip=()):
             compare(name + "/" + k, rec[k], want, grad_rtol or rtol, grad_atol or atol)
         else:
             compare(name + "/" + k, rec[k], want, rtol, atol)
+
+
+# ---------------------------------------------------------------------------------------------
+# measured-error ledger: every GPU parity comparison records its worst error relative to the tensor's scale; conftest.py
+# writes the ledger to gpurun_out/parity_errors.json at the end of the session (copied to profiles/ per round).
+# ---------------------------------------------------------------------------------------------
+ERRORS = {}
+
+
+def scaled_error(name, got, want):
+    """max |got - want| / (max |want| + 1e-6) over the finite entries, after checking shape and the inf / nan pattern."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), "%s: inf/nan pattern differs" % name
+    if not fin.any():
+        return 0.0
+    return float(np.abs(got[fin] - want[fin]).max() / (np.abs(want[fin]).max() + 1e-6))
+
+
+def record_error(case, mode, key, rel, tol):
+    ERRORS.setdefault(case, {}).setdefault(mode, {})[key] = {"rel_err": float("%.3e" % rel), "tol": tol}

@@ -57,8 +57,18 @@ def _worker(rank, world, port, out_dir):
         losses = model(dict(_shard(rank)), method="train")
         sum(l.mean() for l in losses).backward()
         sync.finish()
-        torch.save({"grads": {n: p.grad for n, p in model.named_parameters()},
-                    "params": {n: p.detach() for n, p in model.named_parameters()}}, os.path.join(out_dir, "rank%d.pt" % rank))
+        rec = {"grads": {n: p.grad.clone() for n, p in model.named_parameters()},
+               "params": {n: p.detach().clone() for n, p in model.named_parameters()}}
+        # the reduced gradients ARE views of the flat buckets (nothing is copied back)
+        assert all(p.grad.data_ptr() == v.data_ptr() for b in sync.buckets for (p, _, _), v in zip(b["items"], b["views"]))
+        # ranks with DIFFERENT graphs: rank 1 trains the selection head only (Masque 'ps_train'), so the decoder's hooks never
+        # fire there and its buckets are flushed by finish(); both ranks must still issue the same sequence of collectives
+        model.zero_grad()
+        losses = model(dict(_shard(rank)), method="train" if rank == 0 else "ps_train")
+        sum(l.mean() for l in losses).backward()
+        sync.finish()
+        rec["grads_mixed"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        torch.save(rec, os.path.join(out_dir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -77,3 +87,9 @@ def test_gradsync_world2_gloo(tmp_path):
         want = 2.0 * 0.5 * (g0[n] + g1[n])  # micro-step + boundary step, each averaged over 2 ranks
         assert torch.allclose(r0["grads"][n], want, rtol=1e-5, atol=1e-7), n
         assert torch.equal(r0["grads"][n], r1["grads"][n]), "ranks disagree on " + n
+    ref.zero_grad()
+    sum(l.mean() for l in ref(dict(_shard(1)), method="ps_train")).backward()
+    for n, p in ref.named_parameters():
+        g1 = torch.zeros_like(p) if p.grad is None else p.grad
+        assert torch.allclose(r0["grads_mixed"][n], 0.5 * (g0[n] + g1), rtol=1e-5, atol=1e-7), "mixed graphs: " + n
+        assert torch.equal(r0["grads_mixed"][n], r1["grads_mixed"][n]), "ranks disagree on " + n

@@ -346,11 +346,11 @@ def test_fused_attention_matches_unfused_and_reference(N, h, Lq, Lk, d, causal):
     from case_rg_amd import _abi, config
     ops = _ops()
     assert _abi.lib.case_attention_supported(d)
-    ops.FUSE_FORWARD_WITHOUT_BACKWARD = True  # head_dim 320: keep the fused forward kernel (+ recompute backward) under test
+    ops.ATTENTION_MODE = "fused"  # also head sizes whose backward is not fused: fused forward + recompute backward under test
     try:
         _fused_attention_case(ops, _abi, config, N, h, Lq, Lk, d, causal)
     finally:
-        ops.FUSE_FORWARD_WITHOUT_BACKWARD = False
+        ops.ATTENTION_MODE = "auto"
 
 
 def _fused_attention_case(ops, _abi, config, N, h, Lq, Lk, d, causal):
@@ -481,25 +481,25 @@ def test_linear_wide_output_backward_splits_reduction():
     _close(w.grad, wr.grad, 2e-2, "dW next to split-K dX")
 
 
-class _TilePolicy:
-    """case_gemm_tile_policy for the duration of a block (0 = 128x128 only, 2 = 256x256 whenever eligible)."""
+class _Tile:
+    """CaseGemmDesc.tile for the duration of a block (128 = 128x128 only, 256 = 256x256 whenever eligible)."""
 
-    def __init__(self, policy):
-        self.policy = policy
+    def __init__(self, tile):
+        self.tile = tile
 
     def __enter__(self):
-        from case_rg_amd import _abi
-        _abi.call("case_gemm_tile_policy", self.policy)
+        from case_rg_amd import ops
+        ops.GEMM_TILE = self.tile
 
     def __exit__(self, *exc):
-        from case_rg_amd import _abi
-        _abi.call("case_gemm_tile_policy", 1)
+        from case_rg_amd import ops
+        ops.GEMM_TILE = 0
 
 
 def _gemm_both_tilings(fn):
-    with _TilePolicy(0):
+    with _Tile(128):
         small = fn()
-    with _TilePolicy(2):
+    with _Tile(256):
         large = fn()
     torch.cuda.synchronize()
     return small, large

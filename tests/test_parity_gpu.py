@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import cases
-from helpers import load_golden, to_np
+from helpers import load_golden, record_error, scaled_error, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -24,19 +24,15 @@ def ns():
 
 
 def _scaled_close(name, got, want, tol):
-    got = np.asarray(got, dtype=np.float64)
-    want = np.asarray(want, dtype=np.float64)
-    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
-    fin = np.isfinite(want)
-    assert np.array_equal(np.isfinite(got), fin), "%s: inf/nan pattern differs" % name
-    if not fin.any():
-        return
-    scale = np.abs(want[fin]).max() + 1e-6
-    err = np.abs(got[fin] - want[fin]).max()
-    assert err <= tol * scale, "%s: max err %.3e, scale %.3e (%.2e relative, tol %.0e)" % (name, err, scale, err / scale, tol)
+    case, _, key = name.partition("/")
+    rel = scaled_error(name, got, want)
+    record_error(case, "fp32", key, rel, tol)
+    assert rel <= tol, "%s: %.2e relative to the tensor's scale (tol %.0e)" % (name, rel, tol)
 
 
-def _check(name, rec, tol=1e-3, grad_tol=2e-3):
+# bars: 1e-3 of each tensor's scale (north star), gradients included.  Weights / EMA after Adam steps get 3e-3: Adam divides
+# by sqrt(v), which turns a 1e-4 relative gradient difference on a near-zero gradient element into a visible step difference.
+def _check(name, rec, tol=1e-3, grad_tol=1e-3):
     golden = load_golden(name)
     assert set(rec) == set(golden), "case %s: keys differ: %s" % (name, set(rec) ^ set(golden))
     for k, want in golden.items():
@@ -47,11 +43,13 @@ def _check(name, rec, tol=1e-3, grad_tol=2e-3):
             assert np.array_equal(got, want), "%s/%s: integer mismatch" % (name, k)
         elif k == "margin":
             continue
+        elif k.startswith(("w_slice", "ema_slice")):
+            _scaled_close(name + "/" + k, got, want, 3e-3)
         else:
             _scaled_close(name + "/" + k, got, want, grad_tol if k.startswith("g") else tol)
 
 
-MODULE_CASES = [n for n in cases.CASES if n not in cases.MODEL_CASES]
+MODULE_CASES = [n for n in cases.CASES if n not in cases.MODEL_CASES and n not in cases.PROD_CASES]
 
 
 @pytest.mark.parametrize("name", MODULE_CASES)
@@ -82,7 +80,7 @@ def test_greedy_ids_exact_and_rank_scores(ns, name):
                 name, b, t, got[b, t], want[b, t], margin[b, t])
             checked += 1
     assert checked >= want.size // 2, "too few decisive positions were checked"
-    _scaled_close(name + "/margin", to_np(rec["margin"]), margin, 5e-3)
+    _scaled_close(name + "/margin", to_np(rec["margin"]), margin, 2e-3)
 
 
 def test_product_matches_oracle_on_fresh_inputs(ns):
@@ -100,13 +98,16 @@ def test_product_matches_oracle_on_fresh_inputs(ns):
     sum(w.mean() for w in want).backward()
     sum(g.mean() for g in got).backward()
     rp, pp = dict(ref.named_parameters()), dict(prod.named_parameters())
-    worst = 0.0
+    worst, worst_name = 0.0, ""
     for n_, p in rp.items():
         g = pp[n_].grad
         assert g is not None, "no gradient for " + n_
         scale = p.grad.abs().max().item() + 1e-8
-        worst = max(worst, (g.cpu() - p.grad).abs().max().item() / scale)
-    assert worst <= 5e-3, "worst relative gradient error %.3e" % worst
+        rel = (g.cpu() - p.grad).abs().max().item() / scale
+        if rel > worst:
+            worst, worst_name = rel, n_
+    record_error("fresh_inputs_vs_oracle", "fp32", "worst_gradient:" + worst_name, worst, 2e-3)
+    assert worst <= 2e-3, "worst relative gradient error %.3e (%s)" % (worst, worst_name)
 
 
 def test_bf16_mode_runs_and_is_close(ns):

@@ -26,15 +26,15 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
     M = 122880
     dt = torch.bfloat16
-    for policy in (0, 2):
-        A.call("case_gemm_tile_policy", policy)
+    for policy in (128, 256):
+        ops.GEMM_TILE = policy
         for K in (64, 128, 256, 512, 1024, 2048):
             x = torch.randn(M, K, device="cuda").to(dt)
             w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
             y = torch.empty(M, N, device="cuda", dtype=dt)
             t = timeit(lambda: ops.gemm(x, w, y, M, N, K, K, K, N))
-            print("policy %d  N=%d K=%5d  %8.3f ms  %7.1f TFLOP/s" % (policy, N, K, t * 1e3, 2.0 * M * N * K / t / 1e12))
-    A.call("case_gemm_tile_policy", 1)
+            print("tile %d  N=%d K=%5d  %8.3f ms  %7.1f TFLOP/s" % (policy, N, K, t * 1e3, 2.0 * M * N * K / t / 1e12))
+    ops.GEMM_TILE = 0
 
 
 if __name__ == "__main__":
