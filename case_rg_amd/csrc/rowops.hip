@@ -387,8 +387,9 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const CaseSoftmaxDesc 
 // bf16 rows of up to 1024 columns (C % 8 == 0): one wave per row, the row lives in registers (NCH 16-byte chunks per lane),
 // one global read and one write per element.  The scalar kernels above read every row three times with 2-byte accesses
 // (1.3 TB/s on the 384-wide attention rows of the unfused head_dim-320 backward).
-template <int NCH>
-__global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const CaseSoftmaxDesc d, const bf16_t* __restrict__ x,
+// The forward also takes f32 rows (the unfused attention keeps its scores in f32 and writes bf16 probabilities).
+template <typename TI, int NCH>
+__global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const CaseSoftmaxDesc d, const TI* __restrict__ x,
                                                               const uint8_t* __restrict__ col_valid,
                                                               const uint8_t* __restrict__ row_valid, bf16_t* __restrict__ p_out,
                                                               bf16_t* __restrict__ y_out) {
@@ -407,7 +408,17 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const CaseSoftmaxD
     for (int j = 0; j < NCH; ++j) {
       const int64_t c0 = (int64_t)(lane + 64 * j) * 8;
       const bool in = c0 < d.C;
-      if (in) Vec16<bf16_t>::load(x + row * d.C + c0, v[j]);
+      if (in) {
+        if constexpr (sizeof(TI) == 2) {
+          Vec16<bf16_t>::load(x + row * d.C + c0, v[j]);
+        } else {
+          float lo[4], hi[4];
+          Vec16<float>::load(x + row * d.C + c0, lo);
+          Vec16<float>::load(x + row * d.C + c0 + 4, hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[j][e] = lo[e]; v[j][4 + e] = hi[e]; }
+        }
+      }
       uint64_t cvw = ~0ull;
       if (in && cv) cvw = *reinterpret_cast<const uint64_t*>(cv + c0);
 #pragma unroll
@@ -480,14 +491,14 @@ template <typename TI, typename TO>
 int softmax_launch(const CaseSoftmaxDesc* d, bool fwd, const void* a, const uint8_t* cv, const uint8_t* rv, void* b,
                    void* c, hipStream_t s) {
   const int64_t total = d->outer * d->inner * d->R;
-  if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2) {
-    if (d->C % 8 == 0 && d->C <= 1024 && aligned16(a) && aligned16(b) && aligned16(c) && (!cv || d->C % 8 == 0)) {
+  if constexpr (sizeof(TO) == 2) {
+    if ((fwd || sizeof(TI) == 2) && d->C % 8 == 0 && d->C <= 1024 && aligned16(a) && aligned16(b) && aligned16(c)) {
       const int grid = grid_for(total, 4, 1, 256 * 16);
       if (d->C <= 512) {
-        if (fwd) hipLaunchKernelGGL((softmax_fwd_vec_kernel<1>), dim3(grid), dim3(256), 0, s, *d, (const bf16_t*)a, cv, rv, (bf16_t*)b, (bf16_t*)c);
+        if (fwd) hipLaunchKernelGGL((softmax_fwd_vec_kernel<TI, 1>), dim3(grid), dim3(256), 0, s, *d, (const TI*)a, cv, rv, (bf16_t*)b, (bf16_t*)c);
         else hipLaunchKernelGGL((softmax_bwd_vec_kernel<1>), dim3(grid), dim3(256), 0, s, *d, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)c);
       } else {
-        if (fwd) hipLaunchKernelGGL((softmax_fwd_vec_kernel<2>), dim3(grid), dim3(256), 0, s, *d, (const bf16_t*)a, cv, rv, (bf16_t*)b, (bf16_t*)c);
+        if (fwd) hipLaunchKernelGGL((softmax_fwd_vec_kernel<TI, 2>), dim3(grid), dim3(256), 0, s, *d, (const TI*)a, cv, rv, (bf16_t*)b, (bf16_t*)c);
         else hipLaunchKernelGGL((softmax_bwd_vec_kernel<2>), dim3(grid), dim3(256), 0, s, *d, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)c);
       }
       return case_check_launch(fwd ? "case_softmax_fwd" : "case_softmax_bwd");

@@ -44,6 +44,13 @@ def _valid(seed, rows, length, min_len=2):
     return torch.from_numpy(np.arange(length)[None, :] < lens[:, None])
 
 
+def _act(ns, t):
+    """Float inputs of a module-level case in the namespace's activation dtype (the HIP modules compute in the dtype of their
+    input; ``act_dtype`` is set by the bf16 modes of tests/test_parity_prod_gpu.py and absent for the reference / oracle)."""
+    dt = getattr(ns, "act_dtype", None)
+    return t if dt is None else t.to(dt)
+
+
 def _probe(outs, seed=7):
     """Scalar sum(out * fixed random probe) over all float outputs (drives the gradient checks)."""
     total = 0.0
@@ -251,7 +258,7 @@ def _model_grads(m, losses, names, strided=False):
     out = {}
     for n, g in zip(names, gs):
         g = torch.zeros_like(params[n]) if g is None else g
-        out["gnorm_" + n] = g.norm().reshape(1)
+        out["gnorm_" + n] = g.double().norm().float().reshape(1)  # f64: an f32 norm over 2e7 elements is itself only good to ~5e-4
         out["gslice_" + n] = _strided(g, 256) if strided else g.reshape(-1)[:64].clone()
     return out
 
@@ -426,7 +433,7 @@ def case_trainer_traj(ns, dev):
     rec["losses"] = torch.tensor(losses, dtype=torch.float32)
     rec["lr"] = torch.tensor(sched.get_last_lr(), dtype=torch.float32)
     for n in TRAINER_NAMES:
-        rec["w_norm_" + n] = params[n].detach().norm().reshape(1)
+        rec["w_norm_" + n] = params[n].detach().double().norm().float().reshape(1)
         rec["w_slice_" + n] = _strided(params[n])
         rec["ema_slice_" + n] = _strided(trainer.ema.shadow[n])
     rec["rank"] = torch.cat([out["rank"] for _, out in preds])
@@ -444,7 +451,7 @@ def _sample_rows(t, step=16):
 
 def case_prod_enc_layer(ns, dev):
     m = _mod(ns.TransformerEncoderLayer(512, 8, dim_feedforward=512, dropout=0.1, activation="gelu"), 181, dev)
-    x = _rand(182, 384, 2, 512).to(dev)
+    x = _act(ns, _rand(182, 384, 2, 512).to(dev))
     pad = ~_valid(183, 2, 384, min_len=192).to(dev)
     pad[1, 300:] = True
     with torch.no_grad():
@@ -454,7 +461,7 @@ def case_prod_enc_layer(ns, dev):
 
 def case_prod_block_5h(ns, dev):
     m = _mod(ns.TransformerBlock(8, 2560, 512), 191, dev)
-    x = _rand(192, 1, 2, 384, 2560).to(dev)
+    x = _act(ns, _rand(192, 1, 2, 384, 2560).to(dev))
     valid = _valid(193, 2, 384, min_len=192).reshape(1, 2, 384).clone()
     valid[0, 1, 250:] = False
     valid = valid.to(dev)
@@ -512,7 +519,7 @@ def case_prod_masque_train(ns, dev):
 # ---------------------------------------------------------------------------------------------
 def _cfg5_block(ns, dev, seed, width_in):
     m = _mod(ns.TransformerBlock(8, width_in, 768), seed, dev)
-    x = _rand(seed + 1, 1, 2, 512, width_in).to(dev).requires_grad_()
+    x = _act(ns, _rand(seed + 1, 1, 2, 512, width_in).to(dev)).requires_grad_()
     valid = _valid(seed + 2, 2, 512, min_len=256).reshape(1, 2, 512).clone()
     valid[0, 1, 300:] = False
     valid = valid.to(dev)
@@ -537,8 +544,8 @@ def case_cfg5_dec_layer_long_memory(ns, dev):
     the long-memory cross-attention (common/TransformerDecoder.py:81-82) at head_dim 96."""
     m = _mod(ns.TransformerDecoderLayer(768, 8, dim_feedforward=768, dropout=0.1, activation="gelu"), 251, dev)
     T, S = 40, 20480
-    tgt = _rand(252, T, 1, 768).to(dev).requires_grad_()
-    mem = _rand(253, S, 1, 768).to(dev).requires_grad_()
+    tgt = _act(ns, _rand(252, T, 1, 768).to(dev)).requires_grad_()
+    mem = _act(ns, _rand(253, S, 1, 768).to(dev)).requires_grad_()
     tpad = torch.zeros(1, T, dtype=torch.bool)
     tpad[0, 33:] = True
     mpad = torch.zeros(1, S, dtype=torch.bool)
@@ -557,3 +564,4 @@ def case_cfg5_dec_layer_long_memory(ns, dev):
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
 PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory")
+PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too

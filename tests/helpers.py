@@ -68,5 +68,17 @@ def scaled_error(name, got, want):
     return float(np.abs(got[fin] - want[fin]).max() / (np.abs(want[fin]).max() + 1e-6))
 
 
-def record_error(case, mode, key, rel, tol):
-    ERRORS.setdefault(case, {}).setdefault(mode, {})[key] = {"rel_err": float("%.3e" % rel), "tol": tol}
+def l2_error(got, want):
+    """||got - want|| / ||want|| over the finite entries."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    fin = np.isfinite(want)
+    den = np.linalg.norm(want[fin])
+    return float(np.linalg.norm(got[fin] - want[fin]) / den) if den > 0 else float(np.linalg.norm(got[fin]))
+
+
+def record_error(case, mode, key, rel, tol, l2=None):
+    rec = {"rel_err": float("%.3e" % rel), "tol": tol}
+    if l2 is not None:
+        rec["l2_err"] = float("%.3e" % l2)
+    ERRORS.setdefault(case, {}).setdefault(mode, {})[key] = rec

@@ -9,13 +9,19 @@ S = 20 480) were captured from the reference itself (tests/golden/gen_golden.py)
 
 so ``gemm256_kernel``, ``fa_fwd`` / ``fa_bwd_*`` and the vector softmax run inside a test whose expected values came from the
 reference.  Every comparison's measured error goes to gpurun_out/parity_errors.json (committed per round under profiles/).
-bf16 bars are set from those measurements (about 2x the worst observed), per kind of tensor -- not a blanket figure."""
+
+bf16 bars are set from those measurements (1.5-2x the worst observed, profiles/r02_parity_errors.json), per kind of tensor:
+outputs / losses by the largest element error relative to the tensor's scale; gradients by relative L2 error.  Gradients
+that pass through a ReLU (the TransformerBlocks, reference common/TransformerBlock.py:17-18) differ from an f32 run by 4-5 %
+per block in ANY bf16 implementation: bf16 rounding flips the sign of ~0.1 % of the pre-activations and each flip switches
+a whole gradient element on or off (tools/debug_bf16_block.py: 4.6 % with ReLU, 0.5 % with GELU in the same block, same
+kernels).  ``test_bf16_block_gradient_error_is_the_relu_mask`` keeps that attribution under test."""
 import numpy as np
 import pytest
 import torch
 
 import cases
-from helpers import load_golden, record_error, scaled_error, to_np
+from helpers import l2_error, load_golden, record_error, scaled_error, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -25,12 +31,15 @@ MODES = {
     "bf16_large_fused": dict(dtype=torch.bfloat16, tile=256, attn="fused"),
     "bf16_small_unfused": dict(dtype=torch.bfloat16, tile=128, attn="unfused"),
 }
-# bars relative to each tensor's scale: (outputs / losses, gradients)
-BARS = {"fp32": (1e-3, 1e-3), "bf16_auto": (3e-2, 6e-2), "bf16_large_fused": (3e-2, 6e-2), "bf16_small_unfused": (3e-2, 6e-2)}
+# bf16 bars per case: (outputs / losses: max error relative to the tensor's scale, gradients: relative L2 error)
+BF16_BARS = {"prod_case_train": (2e-2, 0.2), "prod_masque_train": (2e-2, 0.2),           # 8 + 5 (+ 5) ReLU blocks in the graph
+             "cfg5_block_5h": (1.5e-2, 0.08), "cfg5_block_h": (1.5e-2, 0.08),            # one ReLU block
+             "cfg5_dec_layer_long_memory": (2e-2, 0.02),                                # GELU only
+             "prod_enc_layer": (1.5e-2, None), "prod_block_5h": (1.5e-2, None)}
 
 
 HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
-             "cfg5_dec_layer_long_memory": (96,)}
+             "cfg5_dec_layer_long_memory": (96,), "prod_enc_layer": (64,), "prod_block_5h": (320,)}
 
 
 class _Mode:
@@ -62,26 +71,30 @@ class _Mode:
 
 
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("name", list(cases.PROD_CASES))
+@pytest.mark.parametrize("name", list(cases.PROD_CASES + cases.PROD_FORWARD_CASES))
 def test_production_shape_case_matches_reference_fixture(name, mode):
     import case_rg_amd
     with _Mode(mode) as m:
-        rec = cases.CASES[name](case_rg_amd.namespace(), torch.device("cuda"))
+        ns = case_rg_amd.namespace()
+        ns.act_dtype = MODES[mode]["dtype"]
+        rec = cases.CASES[name](ns, torch.device("cuda"))
         torch.cuda.synchronize()
     golden = load_golden(name)
     assert set(rec) == set(golden), "case %s: keys differ: %s" % (name, set(rec) ^ set(golden))
-    tol_out, tol_grad = BARS[mode]
+    tol_out, tol_grad = (1e-3, 1e-3) if mode == "fp32" else BF16_BARS[name]
     failures = []
     for k, want in golden.items():
         got = to_np(rec[k])
         if want.dtype.kind in "biu":
             assert np.array_equal(got, want), "%s/%s: integer / bool mismatch" % (name, k)
             continue
-        tol = tol_grad if k.startswith("g") else tol_out
-        rel = scaled_error("%s/%s" % (name, k), got, want)
-        record_error(name, mode, k, rel, tol)
-        if rel > tol:
-            failures.append("%s: %.2e > %.0e" % (k, rel, tol))
+        is_grad = k.startswith("g")
+        tol = tol_grad if is_grad else tol_out
+        rel, l2 = scaled_error("%s/%s" % (name, k), got, want), l2_error(got, want)
+        record_error(name, mode, k, rel, tol, l2)
+        measured = l2 if (is_grad and mode != "fp32" and not k.startswith("gnorm")) else rel
+        if measured > tol:
+            failures.append("%s: %.2e > %.0e" % (k, measured, tol))
     assert not failures, "%s [%s]: %s" % (name, mode, "; ".join(failures))
     # the mode really exercised the kernels it is named for
     if mode == "bf16_large_fused":
@@ -92,5 +105,31 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
             built, m.calls.get("case_attention_fwd", 0))
     if mode == "bf16_small_unfused":
         assert 256 not in m.tiles and m.calls.get("case_attention_fwd", 0) == 0
-    if mode == "bf16_auto" and name.startswith("prod_"):
+    if mode == "bf16_auto" and name.endswith("_train"):
         assert 256 in m.tiles and m.calls.get("case_attention_bwd", 0) > 0, "bench-mode kernels (gemm256, fa_bwd) did not run"
+
+
+def test_bf16_block_gradient_error_is_the_relu_mask():
+    """The same TransformerBlock (cfg 5 width 768, head_dim 96, L 512) in bf16 against the f32 CPU oracle: with the reference's
+    ReLU the gradients differ by a few per cent (sign flips of near-zero pre-activations), with a smooth activation by well
+    under 1.5 % -- same kernels, same inputs.  Pins the attribution the bf16 gradient bars above rely on."""
+    import torch.nn.functional as F
+    import case_rg_amd
+    import oracle
+
+    def run(ns, dev, act, dt):
+        m = cases._mod(ns.TransformerBlock(8, 768, 768, activation=act), 231, dev)
+        x = cases._rand(232, 1, 2, 512, 768).to(dev).to(dt).requires_grad_()
+        valid = cases._valid(233, 2, 512, min_len=256).reshape(1, 2, 512).to(dev)
+        g = torch.autograd.grad(cases._probe([m(x, valid)]), [x, m.self_attn.in_proj_weight, m.linear1.weight, m.norm2.weight])
+        return [t.detach().float().cpu() for t in g]
+
+    worst = {}
+    for act, label in ((F.relu, "relu"), (F.gelu, "gelu")):
+        want = run(oracle, torch.device("cpu"), act, torch.float32)
+        with _Mode("bf16_auto"):
+            got = run(case_rg_amd.namespace(), torch.device("cuda"), act, torch.bfloat16)
+        worst[label] = max(((a - b).norm() / b.norm()).item() for a, b in zip(got, want))
+        record_error("bf16_block_768", "bf16_auto", "worst_gradient_l2:" + label, worst[label], 0.08 if label == "relu" else 1.5e-2)
+    assert worst["gelu"] <= 1.5e-2 and worst["relu"] <= 0.08, worst
+    assert worst["relu"] > 2.0 * worst["gelu"], "the ReLU attribution no longer holds: %s" % worst
