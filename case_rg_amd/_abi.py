@@ -47,6 +47,8 @@ SIGNATURES = {
     "case_softmax_bwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr],
     "case_attention_supported": [i64],
     "case_attention_fwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_attention_splitkv_workspace": [C.POINTER(AttnDesc), i32, C.POINTER(i64)],
+    "case_attention_fwd_splitkv": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "case_attention_bwd_supported": [i64],
     "case_attention_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],

@@ -71,6 +71,7 @@ class CumulativeTrainer(object):
                 self.sync.finish()
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1)
             optimizer.step()
+            ops.invalidate_param_cache()  # optimizers that write through p.data leave _version alone
             self.ema.update()
             if scheduler is not None:
                 scheduler.step()
@@ -115,6 +116,7 @@ class CumulativeTrainer(object):
                 self.sync.no_sync(False)
                 self.sync.finish()
             optimizer.step()
+            ops.invalidate_param_cache()
             if scheduler is not None:
                 scheduler.step()
             optimizer.zero_grad()

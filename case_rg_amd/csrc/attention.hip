@@ -1,35 +1,48 @@
 // K4/K5/K6 fused multi-head attention for gfx950 (bf16 in, f32 accumulate): no [L, L] score tensor ever reaches HBM.
 //
-// All four kernels share one skeleton.  One side of the attention matrix is STATIONARY: a wave keeps 32 of its
-// rows (queries for fwd / dQ, keys for dK / dV) as MFMA B-operand fragments in registers, ONE ROW PER LANE, so every
-// per-row quantity (running max / sum, log-sum-exp, delta) is lane-local.  The other side STREAMS through LDS in
-// tiles of TS rows; products are oriented so that the 32x32 accumulator of the first product (streamed row index in
-// the registers, stationary row index on the lanes) is, after bf16 packing, directly the B operand of the second
-// product -- no lane exchange and no LDS round trip (v_mfma_f32_32x32x16_bf16, accumulator registers 8s..8s+7 form
-// the fragment of k-step s).  Output accumulators are transposed ([d][stationary row]): 16 f32 registers per
-// 32-wide slice of the head dimension.
+// All kernels share one skeleton.  One side of the attention matrix is STATIONARY: a wave keeps 32 of its rows (queries
+// for fwd / dQ, keys for dK / dV) as MFMA B-operand fragments in registers, ONE ROW PER LANE, so every per-row quantity
+// (running max / sum, log-sum-exp, delta) is lane-local.  The other side STREAMS through LDS in tiles of TS rows; products
+// are oriented so that the 32x32 accumulator of the first product (streamed row index in the registers, stationary row
+// index on the lanes) is, after bf16 packing, directly the B operand of the second product -- no lane exchange and no LDS
+// round trip (v_mfma_f32_32x32x16_bf16, accumulator registers 8s..8s+7 form the fragment of k-step s).  Output
+// accumulators are transposed ([d][stationary row]): 16 f32 registers per 32-wide slice of the head dimension.
 //
 //   fwd : S^T = K Q^T (A = K rows from LDS, B = Q^T regs) -> online softmax over the streamed keys (lane-local)
 //         O^T += V^T P^T   (A = V^T via ds_read_b64_tr_b16 of the V tile, B = packed P^T)
 //   dQ  : S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
 //   dK  : S = Q K^T (A = Q rows, B = K regs), dP = dO V^T (B = V regs), dS ; dK^T += Q^T dS
 //   dV  : S = Q K^T, P ; dV^T += dO^T P
-// Recomputing S in each backward kernel costs 8 instead of 5 products per tile, but keeps the register budget of the
-// head_dim-320 blocks (5H/8, 73 % of CaSE's FLOPs) inside one wave per SIMD: 80 (stationary fragments) [+80] + 160
-// (output accumulators) + tiles.
+//
+// HEAD-DIM SPLIT (head_dim 320 = 5H/8 at cfg 2 -- 73 % of CaSE's FLOPs -- and 480 at cfg 5).  A wave that owned a whole
+// 320-wide row block needs 80 (stationary fragments) + 160 (output accumulators) registers before any tile: one wave per
+// SIMD, and it ran register- and latency-bound at 207 TFLOP/s.  Here NS waves share one block of 32 stationary rows:
+// wave `split` keeps only head-dim slice [split DH, (split + 1) DH), DH = D / NS (160 for both 320 and 480), of the
+// stationary fragments and of the output accumulators.  A product that contracts over the head dim (S, dP) is then a
+// PARTIAL sum per wave: the NS partial 32x32 f32 tiles are exchanged through 4 KiB LDS slots and summed in a fixed order
+// (so all NS waves hold bit-identical scores and take identical softmax decisions), every wave repeats the lane-local
+// softmax arithmetic, and the second product is computed for the wave's own slice only.  120-170 registers per wave ->
+// two waves per SIMD, MFMA work split evenly, 8 KiB of extra LDS traffic per 32x32 tile.  dK and dV are separate
+// kernels at split head dims (each keeps one accumulator slice: two waves per SIMD); at NS = 1 they share one.
 //
 // LDS images (bf16): row-read operand [TS][D*2 + 16 B] (row stride = 36 dwords mod 64 -> conflict-free ds_read_b128);
-// transposed-read operand [TS][stride = 48 dwords mod 64] (four k-rows of a ds_read_b64_tr_b16 block land on
-// disjoint bank windows).  Tiles are double-buffered; the next tile's global loads are issued before the MFMA phase
-// and written to the other buffer after it (one barrier per tile).
+// transposed-read operand [TS][stride = 48 dwords mod 64] (four k-rows of a ds_read_b64_tr_b16 block land on disjoint
+// bank windows).  Forward tiles are double-buffered; the next tile's global loads are issued before the MFMA phase and
+// written to the other buffer after it.
 //
-// Dropout uses the same counter RNG and the same element index ((n*h + head)*Lq + q)*Lk + k as the unfused
-// softmax kernel, so fused and unfused paths draw identical masks.
+// SPLIT-KV forward (long memories with few (sequence, head) pairs: cfg 5 cross-attention, 40 queries x 20 480 keys):
+// the key range is cut into `ksplit` chunks handled by different workgroups, each writes an unnormalised partial
+// (O~ f32, running max, running sum) to caller-owned workspace, and fa_combine_kernel merges them -- so a launch has
+// N x heads x ksplit workgroups streaming K/V instead of N x heads.
+//
+// Dropout uses the same counter RNG and the same element index ((n*h + head)*Lq + q)*Lk + k as the unfused softmax
+// kernel, so fused and unfused paths draw identical masks.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
@@ -40,15 +53,25 @@ struct FaArgs {
   bf16_t* o; int64_t ldo, so;                          // fwd output [N, Lq, heads*D]
   float* lse;                                          // [N, heads, Lq]  (fwd: out; bwd: in)
   const uint8_t* key_valid;                            // [N, Lk] or null
+  // split-KV forward only
+  float* part_o;                                       // [ksplit][N*heads*Lq][D] unnormalised O
+  float* part_ml;                                      // [ksplit][N*heads*Lq][2] (running max in the base-2 domain, running sum)
+  int ksplit, kchunk;                                  // key chunks per (sequence, head); keys per chunk (multiple of TS)
   // backward only
   const bf16_t* dout; int64_t lddo, sdo;               // dO [N, Lq, heads*D]
   const float* delta;                                  // [N, heads, Lq] = rowsum(dO * O)
-  float* dq; float* dk; float* dv;                     // f32 gradient slices written in the source layout
-  int64_t lddq, sdq, lddk, sdk, lddv, sdv;
-  int Lq, Lk, heads, causal, nblk, tiles;
+  int Lq, Lk, heads, causal, nblk, tiles, N;
   float scale, drop_p;
   uint64_t seed, offset;
 };
+
+// Diagnostic builds (-DFAS_STAMPS): wave 0 lane 0 of every workgroup writes s_memtime stamps to the buffer given to
+// case_debug_stamp_buffer(); tools/attn_stamps.py turns them into per-phase shares.  No stamp exists in the shipped library.
+#ifdef FAS_STAMPS
+#define FAS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && a.part_ml) ((unsigned long long*)a.part_ml)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FAS_STAMP(i)
+#endif
 
 __device__ __forceinline__ int xcd_remap(int pid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
@@ -63,19 +86,20 @@ template <int D> struct Geo {
 
 // ---- tile staging: [TS rows][D] bf16 from global (row stride ld) into an LDS image with row stride STRIDE ----------
 // Per-thread state is one 32-bit byte offset per 16-byte chunk (set once); the tile advances through the uniform base
-// pointer, so the prefetch costs no 64-bit address registers inside the main loop.
-template <int D, int TS>
+// pointer, so the prefetch costs no 64-bit address registers inside the main loop.  NT = threads of the workgroup.
+template <int D, int TS, int NT>
 struct Stage {
-  static constexpr int CH = D / 8;              // 16-byte chunks per row
-  static constexpr int NV = TS * CH / 256;      // chunks per thread
-  static_assert(TS * CH % 256 == 0, "tile must be a whole number of 256-thread passes");
+  static constexpr int CH = D / 8;                     // 16-byte chunks per row
+  static constexpr int TOTAL = TS * CH;
+  static constexpr int NV = (TOTAL + NT - 1) / NT;     // chunks per thread
   u32x4 r[NV];
   unsigned off[NV];
   unsigned ok;
   __device__ __forceinline__ void init(int64_t ld) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = threadIdx.x + i * 256;
+      int c = threadIdx.x + i * NT;
+      c = c < TOTAL ? c : TOTAL - 1;
       off[i] = (unsigned)((c / CH) * ld * 2 + (c % CH) * 16);
     }
   }
@@ -84,8 +108,8 @@ struct Stage {
     ok = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int row = (threadIdx.x + i * 256) / CH;
-      const bool in = row < rows_left;
+      const int c = threadIdx.x + i * NT;
+      const bool in = (TOTAL % NT == 0 || c < TOTAL) && (c / CH) < rows_left;
       r[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile_base) + (in ? off[i] : 0u));
       ok |= (in ? 1u : 0u) << i;
     }
@@ -95,8 +119,9 @@ struct Stage {
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = threadIdx.x + i * 256;
-      *reinterpret_cast<u32x4*>(lds + (c / CH) * STRIDE + (c % CH) * 16) = ((ok >> i) & 1u) ? r[i] : z;
+      const int c = threadIdx.x + i * NT;
+      if (TOTAL % NT == 0 || c < TOTAL)
+        *reinterpret_cast<u32x4*>(lds + (c / CH) * STRIDE + (c % CH) * 16) = ((ok >> i) & 1u) ? r[i] : z;
     }
   }
 };
@@ -125,25 +150,47 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds, int row0, int dt) {
   return r;
 }
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-
 // accumulator registers 8*s2 .. 8*s2+7 -> B-operand fragment of k-step s2
 __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
-  u32x4_t w;
+  u32x4 w;
 #pragma unroll
   for (int j = 0; j < 4; ++j) w[j] = f32x2_to_bf16x2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
   return *reinterpret_cast<bf16x8*>(&w);
 }
 
-// stationary fragments: lane (c = l&31, h = l>>5) holds row (row0 + c), head-dim values 16 s + 8 h .. + 7
-template <int D>
-__device__ __forceinline__ void load_stationary(bf16x8 (&f)[D / 16], const bf16_t* base, int64_t ld, int row0, int rows) {
+// stationary fragments of a DW-wide head-dim slice: lane (c = l&31, h = l>>5) holds row (row0 + c), values 16 s + 8 h .. + 7
+template <int DW>
+__device__ __forceinline__ void load_stationary(bf16x8 (&f)[DW / 16], const bf16_t* base, int64_t ld, int row0, int rows) {
   const int l = threadIdx.x & 63;
   int row = row0 + (l & 31);
   row = row < rows ? row : rows - 1;  // clamp: out-of-range lanes compute garbage that is never stored
   const bf16_t* p = base + (int64_t)row * ld + 8 * (l >> 5);
 #pragma unroll
-  for (int s = 0; s < D / 16; ++s) f[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+  for (int s = 0; s < DW / 16; ++s) f[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+}
+
+// ---- partial-tile exchange between the NS waves that share a block of stationary rows ---------------------------------
+// One slot = one wave's 32x32 f32 accumulator, lane-major in four 1 KiB planes (conflict-free b128 accesses).
+constexpr int XSLOT = 1024;  // floats
+__device__ __forceinline__ void x_put(float* slot, const f32x16& a) {
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = {a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+    *reinterpret_cast<f32x4*>(slot + j * 256 + l * 4) = v;
+  }
+}
+// sum of the NS partials in split order (every wave of the group computes the same bits)
+template <int NS>
+__device__ __forceinline__ void x_sum(const float* slot0, f32x16& a) {
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(slot0 + j * 256 + l * 4);
+#pragma unroll
+    for (int o = 1; o < NS; ++o) v += *reinterpret_cast<const f32x4*>(slot0 + o * XSLOT + j * 256 + l * 4);
+    a[4 * j] = v[0]; a[4 * j + 1] = v[1]; a[4 * j + 2] = v[2]; a[4 * j + 3] = v[3];
+  }
 }
 
 // Validity of the TS streamed rows of a tile as a wave-uniform 64-bit mask (bit r = row0 + r is a real, unpadded row):
@@ -177,76 +224,118 @@ __device__ __forceinline__ void rng4(uint64_t seed, uint64_t i0, float (&u)[4]) 
 // streamed row index of accumulator register e in a 32-row tile
 __device__ __forceinline__ int acc_row(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
 
+// transposed accumulators [d][stationary row] of a DW-wide slice -> bf16 row segment
+template <int DW>
+__device__ __forceinline__ void store_transposed(const f32x16 (&acc)[DW / 32], bf16_t* row_ptr, int half, float mul) {
+#pragma unroll
+  for (int dt = 0; dt < DW / 32; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint32_t w0 = f32x2_to_bf16x2(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul);
+      const uint32_t w1 = f32x2_to_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+      *reinterpret_cast<uint2*>(row_ptr + dt * 32 + 8 * g + 4 * half) = make_uint2(w0, w1);
+    }
+}
+
 // =====================================================================================================
-// forward
+// forward.  Workgroup = NQ blocks of 32 queries x NS head-dim slices (64 NS NQ threads).  SPLITKV: blockIdx also selects a
+// key chunk; the unnormalised partial goes to the workspace instead of O / LSE.
 // =====================================================================================================
-template <int D, int TS>
-__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const FaArgs a) {
+template <int D, int NS, int NQ, int TS, int MINW, bool SPLITKV>
+__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs a) {
+  constexpr int NT = 64 * NS * NQ, DH = D / NS, KSW = DH / 16, OB = DH / 32, KT = TS / 32;
+  static_assert(D % NS == 0 && DH % 32 == 0, "head-dim slices must be multiples of 32");
+  static_assert(NS == 1 || KT == 1, "split head dims exchange one 32-key tile per barrier");
   constexpr int KROW = Geo<D>::ROW, VROW = Geo<D>::TRS;
   constexpr int KBYTES = TS * KROW, VBYTES = TS * VROW, BUF = KBYTES + VBYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int pid = xcd_remap(blockIdx.x, a.nblk);
+  float* xbuf = reinterpret_cast<float*>(smem + 2 * BUF);
+  int pid = xcd_remap(blockIdx.x, a.nblk);
+  int kc = 0;
+  if constexpr (SPLITKV) {
+    kc = pid % a.ksplit;
+    pid /= a.ksplit;
+  }
   const int qt = pid % a.tiles, head = (pid / a.tiles) % a.heads, n = pid / (a.tiles * a.heads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-  const int q0 = qt * 128 + wave * 32, qi = q0 + (lane & 31);
+  const int qb = wave / NS, split = wave % NS;
+  const int q0 = qt * (32 * NQ) + qb * 32, qi = q0 + (lane & 31);
 
   const bf16_t* Q = a.q + (int64_t)n * a.sq + head * D;
   const bf16_t* K = a.k + (int64_t)n * a.sk + head * D;
   const bf16_t* V = a.v + (int64_t)n * a.sv + head * D;
   const uint8_t* kv = a.key_valid ? a.key_valid + (int64_t)n * a.Lk : nullptr;
 
-  bf16x8 qf[D / 16];
-  load_stationary<D>(qf, Q, a.ldq, q0, a.Lq);
+  FAS_STAMP(0);
+  bf16x8 qf[KSW];
+  load_stationary<DH>(qf, Q + split * DH, a.ldq, q0, a.Lq);
 
-  f32x16 o[D / 32];
+  f32x16 o[OB];
 #pragma unroll
-  for (int t = 0; t < D / 32; ++t)
+  for (int t = 0; t < OB; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
   float m = -INFINITY, lsum = 0.f;
 
-  int ntiles = (a.Lk + TS - 1) / TS;
-  if (a.causal) {  // keys beyond the last query of this workgroup never contribute
-    const int last = min(a.Lq, qt * 128 + 128) - 1;
-    ntiles = min(ntiles, last / TS + 1);
+  // key range of this workgroup
+  int key_begin = 0, key_end = a.Lk;
+  if constexpr (SPLITKV) {
+    key_begin = kc * a.kchunk;
+    key_end = min(a.Lk, key_begin + a.kchunk);
   }
-  Stage<D, TS> sk, sv;
+  int ntiles = (key_end - key_begin + TS - 1) / TS;
+  if (a.causal) {  // keys beyond the last query of this workgroup never contribute
+    const int last = min(a.Lq, qt * (32 * NQ) + 32 * NQ) - 1;
+    ntiles = max(0, min(ntiles, (last - key_begin) / TS + 1));
+  }
+  K += (int64_t)key_begin * a.ldk;
+  V += (int64_t)key_begin * a.ldv;
+  Stage<D, TS, NT> sk, sv;
   RowMask rm;
   sk.init(a.ldk);
   sv.init(a.ldv);
-  sk.load(K, a.Lk);
-  sv.load(V, a.Lk);
-  rm.fetch(kv, 0, a.Lk);
-  sk.template store<KROW>(smem);
-  sv.template store<VROW>(smem + KBYTES);
-  unsigned long long mask = rm.ballot();
+  unsigned long long mask = 0;
+  if (ntiles > 0) {
+    sk.load(K, key_end - key_begin);
+    sv.load(V, key_end - key_begin);
+    rm.fetch(kv, key_begin, key_end);
+    sk.template store<KROW>(smem);
+    sv.template store<VROW>(smem + KBYTES);
+    mask = rm.ballot();
+  }
   __syncthreads();
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const float scale2 = a.scale * LOG2E;
   const uint64_t rng_row = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi) * (uint64_t)a.Lk;
+  FAS_STAMP(1);
 
   for (int t = 0; t < ntiles; ++t) {
     const char* kb = smem + (t & 1) * BUF;
     const char* vb = kb + KBYTES;
     if (t + 1 < ntiles) {
-      sk.load(K + (int64_t)(t + 1) * TS * a.ldk, a.Lk - (t + 1) * TS);
-      sv.load(V + (int64_t)(t + 1) * TS * a.ldv, a.Lk - (t + 1) * TS);
-      rm.fetch(kv, (t + 1) * TS, a.Lk);
+      sk.load(K + (int64_t)(t + 1) * TS * a.ldk, key_end - key_begin - (t + 1) * TS);
+      sv.load(V + (int64_t)(t + 1) * TS * a.ldv, key_end - key_begin - (t + 1) * TS);
+      rm.fetch(kv, key_begin + (t + 1) * TS, key_end);
     }
     const unsigned long long mrow = mask >> (4 * half);  // bit (e&3) + 8 (e>>2) + 32 kt of this lane's half
 #pragma unroll
-    for (int kt = 0; kt < TS / 32; ++kt) {
-      // ---- S^T tile: 32 keys (registers) x 32 queries (lanes)
+    for (int kt = 0; kt < KT; ++kt) {
+      // ---- S^T tile: 32 keys (registers) x 32 queries (lanes); partial over this wave's head-dim slice
       f32x16 st;
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-      for (int s = 0; s < D / 16; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KROW>(kb, kt * 32, s), qf[s], st, 0, 0, 0);
-        if (D > 128 && (s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the fragment prefetch depth (VGPR budget)
+      for (int s = 0; s < KSW; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KROW>(kb, kt * 32, split * KSW + s), qf[s], st, 0, 0, 0);
+        if (DH > 128 && (s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the fragment prefetch depth (VGPR budget)
+      }
+      if constexpr (NS > 1) {
+        x_put(xbuf + (qb * NS + split) * XSLOT, st);
+        __syncthreads();
+        x_sum<NS>(xbuf + qb * NS * XSLOT, st);
       }
       // ---- mask + online softmax (per lane = per query)
-      const int key0 = t * TS + kt * 32;
+      const int key0 = key_begin + t * TS + kt * 32;
       float mx = -INFINITY;
       // interior tile: every key valid and (causal) not beyond the wave's first query -> no per-element mask work
       const bool all_ok = ((mask >> (32 * kt)) & 0xffffffffull) == 0xffffffffull && (!a.causal || key0 + 31 <= q0);
@@ -268,18 +357,17 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // lazy rescale: the running reference max moves only when some query's tile max exceeds it by more than THR;
       // probabilities then stay below e^THR (fine for the bf16 P operand, l and O accumulate in f32), and the
-      // O-wide rescale (whose accumulators live in AGPRs) runs on a few early tiles only.  The decision precedes the
-      // exponentiation of this tile and follows the previous tile's P V, so every term is scaled exactly once.
+      // O-wide rescale runs on a few early tiles only.  The decision precedes the exponentiation of this tile and
+      // follows the previous tile's P V, so every term is scaled exactly once.
       if (__any(mx > m + RESCALE_THR)) {
         const float m_new = fmaxf(m, mx);
         const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
         lsum *= alpha;
         m = m_new;
 #pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt) {
+        for (int dt = 0; dt < OB; ++dt) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
-          __builtin_amdgcn_sched_barrier(0);  // one 16-register slice at a time through the arch VGPRs
         }
       }
       float ps = 0.f;
@@ -299,15 +387,13 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
           for (int k = 0; k < 4; ++k) st[4 * gq + k] = u[k] >= a.drop_p ? st[4 * gq + k] * keep_scale : 0.f;
         }
       }
-      // ---- O^T += V^T P^T
+      // ---- O^T += V^T P^T  (this wave's head-dim slice)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = pack_acc(st, s2);
 #pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt) {
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<VROW>(vb, kt * 32 + 16 * s2, dt), pf, o[dt], 0, 0, 0);
-          if (D > 128 && (dt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int dt = 0; dt < OB; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<VROW>(vb, kt * 32 + 16 * s2, split * OB + dt), pf, o[dt], 0, 0, 0);
       }
     }
     if (t + 1 < ntiles) {
@@ -319,27 +405,77 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void fa_fwd_kernel(const F
     __syncthreads();
   }
 
-  // ---- finalise: O = O^T / l, LSE = ln 2 * m + log(l)  (m is in the base-2 domain)
+  FAS_STAMP(2);
   lsum += __shfl_xor(lsum, 32, 64);
-  const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-  if (qi < a.Lq) {
-    bf16_t* orow = a.o + (int64_t)n * a.so + (int64_t)qi * a.ldo + head * D;
+  if constexpr (SPLITKV) {
+    // unnormalised partial: O~ (f32), m (base-2 domain), l
+    if (qi < a.Lq) {
+      const int64_t row = ((int64_t)n * a.heads + head) * a.Lq + qi;
+      const int64_t rows = (int64_t)a.N * a.heads * a.Lq;
+      float* po = a.part_o + ((int64_t)kc * rows + row) * D + split * DH;
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
+      for (int dt = 0; dt < OB; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint32_t w0 = f32x2_to_bf16x2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
-        const uint32_t w1 = f32x2_to_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * g + 4 * half) = make_uint2(w0, w1);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(po + dt * 32 + 8 * g + 4 * half) = v;
+        }
+      if (half == 0 && split == 0) {
+        float* ml = a.part_ml + ((int64_t)kc * rows + row) * 2;
+        ml[0] = m;
+        ml[1] = lsum;
       }
-    if (half == 0) a.lse[((int64_t)n * a.heads + head) * a.Lq + qi] = lsum > 0.f ? m * LN2 + __logf(lsum) : -INFINITY;  // natural log
+    }
+  } else {
+    // ---- finalise: O = O^T / l, LSE = ln 2 * m + log(l)  (m is in the base-2 domain)
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    if (qi < a.Lq) {
+      store_transposed<DH>(o, a.o + (int64_t)n * a.so + (int64_t)qi * a.ldo + head * D + split * DH, half, inv);
+      if (half == 0 && split == 0)
+        a.lse[((int64_t)n * a.heads + head) * a.Lq + qi] = lsum > 0.f ? m * LN2 + __logf(lsum) : -INFINITY;  // natural log
+    }
   }
+  FAS_STAMP(3);
+}
+
+// merge of the split-KV partials: one thread per (row, 8 head-dim values)
+template <int D>
+__global__ __launch_bounds__(256) void fa_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                         bf16_t* __restrict__ out, float* __restrict__ lse, int64_t rows, int ksplit,
+                                                         int heads, int Lq, int64_t ldo, int64_t so) {
+  constexpr int CH = D / 8;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * CH) return;
+  const int64_t row = i / CH;  // (n*heads + head)*Lq + q
+  const int c = (int)(i % CH);
+  float mmax = -INFINITY;
+  for (int s = 0; s < ksplit; ++s) mmax = fmaxf(mmax, part_ml[((int64_t)s * rows + row) * 2]);
+  float l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < ksplit; ++s) {
+    const float ms = part_ml[((int64_t)s * rows + row) * 2], ls = part_ml[((int64_t)s * rows + row) * 2 + 1];
+    if (ms == -INFINITY) continue;
+    const float w = __builtin_amdgcn_exp2f(ms - mmax);
+    l += w * ls;
+    const float* po = part_o + ((int64_t)s * rows + row) * D + c * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(po), hi = *reinterpret_cast<const f32x4*>(po + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] += w * lo[e];
+      acc[4 + e] += w * hi[e];
+    }
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  const int64_t q = row % Lq, nh = row / Lq, head = nh % heads, n = nh / heads;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] *= inv;
+  Vec16<bf16_t>::store(out + n * so + q * ldo + head * D + c * 8, acc);
+  if (c == 0) lse[row] = l > 0.f ? mmax * LN2 + __logf(l) : -INFINITY;
 }
 
 // =====================================================================================================
-// backward, head_dim <= 128 (two waves per SIMD): delta, dQ (query-stationary), dK+dV (key-stationary)
+// backward: delta, dQ (query-stationary), dK / dV (key-stationary)
 // =====================================================================================================
-// delta[n, head, q] = sum_d dO[n, q, head, d] * O[n, q, head, d]   (one wave per 64 (row, head) pairs)
+// delta[n, head, q] = sum_d dO[n, q, head, d] * O[n, q, head, d]
 template <int D>
 __global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
                                                        float* __restrict__ delta, int64_t rows, int heads, int Lq) {
@@ -350,7 +486,7 @@ __global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict_
   const bf16_t* a = dout + row * heads * D + head * D;
   const bf16_t* b = out + row * heads * D + head * D;
   float acc = 0.f;
-#pragma unroll
+#pragma unroll 4
   for (int c = 0; c < D; c += 8) {
     const uint4 x = *reinterpret_cast<const uint4*>(a + c), y = *reinterpret_cast<const uint4*>(b + c);
     const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
@@ -363,56 +499,47 @@ __global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict_
   delta[(n * heads + head) * Lq + q] = acc;
 }
 
-// transposed accumulators [d][stationary row] -> bf16 rows of the gradient slice
-template <int D>
-__device__ __forceinline__ void store_transposed(const f32x16 (&acc)[D / 32], bf16_t* row_ptr, int half, float mul) {
-#pragma unroll
-  for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const uint32_t w0 = f32x2_to_bf16x2(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul);
-      const uint32_t w1 = f32x2_to_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
-      *reinterpret_cast<uint2*>(row_ptr + dt * 32 + 8 * g + 4 * half) = make_uint2(w0, w1);
-    }
-}
-
 struct BwdOut {  // bf16 gradient slices, addressed like q / k / v
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
 };
 
 // ---- dQ: stationary queries (lane = query); streams K (row + transposed images) and V (row image) -----------------
-template <int D, int TS>
-__global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(const FaArgs a, const BwdOut g) {
+template <int D, int NS, int NQ, int TS, int MINW>
+__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaArgs a, const BwdOut g) {
+  constexpr int NT = 64 * NS * NQ, DH = D / NS, KSW = DH / 16, OB = DH / 32, KT = TS / 32;
+  static_assert(NS == 1 || KT == 1, "split head dims exchange one 32-key tile per barrier");
   constexpr int RS = Geo<D>::ROW, TR = Geo<D>::TRS;
-  constexpr int KR = 0, KT = TS * RS, VR = KT + TS * TR;
+  constexpr int KR = 0, KTI = TS * RS, VR = KTI + TS * TR, XB = VR + TS * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xbuf = reinterpret_cast<float*>(smem + XB);
   const int pid = xcd_remap(blockIdx.x, a.nblk);
   const int qt = pid % a.tiles, head = (pid / a.tiles) % a.heads, n = pid / (a.tiles * a.heads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-  const int q0 = qt * 128 + wave * 32, qi = q0 + (lane & 31);
+  const int qb = wave / NS, split = wave % NS;
+  const int q0 = qt * (32 * NQ) + qb * 32, qi = q0 + (lane & 31);
   const bf16_t* Q = a.q + (int64_t)n * a.sq + head * D;
   const bf16_t* K = a.k + (int64_t)n * a.sk + head * D;
   const bf16_t* V = a.v + (int64_t)n * a.sv + head * D;
   const bf16_t* DO = a.dout + (int64_t)n * a.sdo + head * D;
   const uint8_t* kv = a.key_valid ? a.key_valid + (int64_t)n * a.Lk : nullptr;
 
-  bf16x8 qf[D / 16], dof[D / 16];
-  load_stationary<D>(qf, Q, a.ldq, q0, a.Lq);
-  load_stationary<D>(dof, DO, a.lddo, q0, a.Lq);
+  bf16x8 qf[KSW], dof[KSW];
+  load_stationary<DH>(qf, Q + split * DH, a.ldq, q0, a.Lq);
+  load_stationary<DH>(dof, DO + split * DH, a.lddo, q0, a.Lq);
   const int64_t stat = ((int64_t)n * a.heads + head) * a.Lq + (qi < a.Lq ? qi : a.Lq - 1);
   const float lse2_q = a.lse[stat] * LOG2E, delta_q = a.delta[stat];  // base-2 domain: p = 2^(scale2 s - lse2)
   const float scale2 = a.scale * LOG2E;
-  f32x16 acc[D / 32];
+  f32x16 acc[OB];
 #pragma unroll
-  for (int t = 0; t < D / 32; ++t)
+  for (int t = 0; t < OB; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   int ntiles = (a.Lk + TS - 1) / TS;
-  if (a.causal) ntiles = min(ntiles, (min(a.Lq, qt * 128 + 128) - 1) / TS + 1);
+  if (a.causal) ntiles = min(ntiles, (min(a.Lq, qt * (32 * NQ) + 32 * NQ) - 1) / TS + 1);
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const uint64_t rng_row = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi) * (uint64_t)a.Lk;
-  Stage<D, TS> sk, sv;
+  Stage<D, TS, NT> sk, sv;
   RowMask rm;
   sk.init(a.ldk);
   sv.init(a.ldv);
@@ -423,19 +550,27 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(const FaArgs a, const
     rm.fetch(kv, t * TS, a.Lk);
     __syncthreads();  // previous tile fully consumed
     sk.template store<RS>(smem + KR);
-    sk.template store<TR>(smem + KT);
+    sk.template store<TR>(smem + KTI);
     sv.template store<RS>(smem + VR);
     const unsigned long long mrow_all = rm.ballot(), mrow = mrow_all >> (4 * half);
     __syncthreads();
 #pragma unroll
-    for (int kt = 0; kt < TS / 32; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
       f32x16 st, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
 #pragma unroll
-      for (int s = 0; s < D / 16; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + KR, kt * 32, s), qf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + VR, kt * 32, s), dof[s], dp, 0, 0, 0);
+      for (int s = 0; s < KSW; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + KR, kt * 32, split * KSW + s), qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + VR, kt * 32, split * KSW + s), dof[s], dp, 0, 0, 0);
+        if (DH > 128 && (s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the fragment prefetch depth (VGPR budget)
+      }
+      if constexpr (NS > 1) {
+        x_put(xbuf + ((qb * 2 + 0) * NS + split) * XSLOT, st);
+        x_put(xbuf + ((qb * 2 + 1) * NS + split) * XSLOT, dp);
+        __syncthreads();
+        x_sum<NS>(xbuf + (qb * 2 + 0) * NS * XSLOT, st);
+        x_sum<NS>(xbuf + (qb * 2 + 1) * NS * XSLOT, dp);
       }
       const int key0 = t * TS + kt * 32;
       if (a.drop_p > 0.f) {
@@ -467,49 +602,62 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dq_kernel(const FaArgs a, const
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 df = pack_acc(st, s2);
 #pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt)
-          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<TR>(smem + KT, kt * 32 + 16 * s2, dt), df, acc[dt], 0, 0, 0);
+        for (int dt = 0; dt < OB; ++dt) {
+          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<TR>(smem + KTI, kt * 32 + 16 * s2, split * OB + dt), df, acc[dt], 0, 0, 0);
+          if (DH > 128 && (dt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
-  if (qi < a.Lq) store_transposed<D>(acc, g.dq + (int64_t)n * a.sq + (int64_t)qi * a.ldq + head * D, half, 1.f);
+  if (qi < a.Lq) store_transposed<DH>(acc, g.dq + (int64_t)n * a.sq + (int64_t)qi * a.ldq + head * D + split * DH, half, 1.f);
 }
 
-// ---- dK + dV: stationary keys (lane = key); streams Q and dO (row + transposed images each) ------------------------
-template <int D, int TS>
-__global__ __launch_bounds__(256, 2) void fa_bwd_dkv_kernel(const FaArgs a, const BwdOut g) {
+// ---- dK / dV: stationary keys (lane = key); streams Q and dO.  WHAT: 3 = both (NS = 1), 1 = dK only, 2 = dV only -------
+template <int D, int NS, int NQ, int TS, int MINW, int WHAT>
+__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const FaArgs a, const BwdOut g) {
+  constexpr bool DO_K = (WHAT & 1) != 0, DO_V = (WHAT & 2) != 0;
+  constexpr int NT = 64 * NS * NQ, DH = D / NS, KSW = DH / 16, OB = DH / 32, KT = TS / 32;
+  static_assert(NS == 1 || KT == 1, "split head dims exchange one 32-query tile per barrier");
   constexpr int RS = Geo<D>::ROW, TR = Geo<D>::TRS;
-  constexpr int QR = 0, QT = TS * RS, OR_ = QT + TS * TR, OT = OR_ + TS * RS, ST = OT + TS * TR;
+  // images: Q rows (S) always; Q transposed (dK); dO rows (dP, for dK); dO transposed (dV)
+  constexpr int QR = 0, QT = TS * RS, OR_ = QT + (DO_K ? TS * TR : 0), OT = OR_ + (DO_K ? TS * RS : 0);
+  constexpr int ST = OT + (DO_V ? TS * TR : 0), XB = ST + 2 * TS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lse_s = reinterpret_cast<float*>(smem + ST);
   float* del_s = lse_s + TS;
+  float* xbuf = reinterpret_cast<float*>(smem + XB);
   const int pid = xcd_remap(blockIdx.x, a.nblk);
   const int ktile = pid % a.tiles, head = (pid / a.tiles) % a.heads, n = pid / (a.tiles * a.heads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-  const int k0 = ktile * 128 + wave * 32, ki = k0 + (lane & 31);
+  const int kblk = wave / NS, split = wave % NS;
+  const int k0 = ktile * (32 * NQ) + kblk * 32, ki = k0 + (lane & 31);
   const bf16_t* Q = a.q + (int64_t)n * a.sq + head * D;
   const bf16_t* K = a.k + (int64_t)n * a.sk + head * D;
   const bf16_t* V = a.v + (int64_t)n * a.sv + head * D;
   const bf16_t* DO = a.dout + (int64_t)n * a.sdo + head * D;
   const bool key_ok = ki < a.Lk && (!a.key_valid || a.key_valid[(int64_t)n * a.Lk + ki]);
 
-  bf16x8 kf[D / 16], vf[D / 16];
-  load_stationary<D>(kf, K, a.ldk, k0, a.Lk);
-  load_stationary<D>(vf, V, a.ldv, k0, a.Lk);
-  f32x16 dk[D / 32], dv[D / 32];
+  bf16x8 kf[KSW], vf[DO_K ? KSW : 1];
+  load_stationary<DH>(kf, K + split * DH, a.ldk, k0, a.Lk);
+  if constexpr (DO_K) load_stationary<DH>(vf, V + split * DH, a.ldv, k0, a.Lk);
+  f32x16 dk[DO_K ? OB : 1], dv[DO_V ? OB : 1];
 #pragma unroll
-  for (int t = 0; t < D / 32; ++t)
+  for (int t = 0; t < (DO_K ? OB : 1); ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dk[t][e] = dv[t][e] = 0.f;
+    for (int e = 0; e < 16; ++e) dk[t][e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < (DO_V ? OB : 1); ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
 
   const int ntiles = (a.Lq + TS - 1) / TS;
-  const int tbegin = a.causal ? (ktile * 128) / TS : 0;  // queries before the first key of this workgroup see none of its keys
+  const int tbegin = a.causal ? (ktile * (32 * NQ)) / TS : 0;  // queries before the first key of this workgroup see none of its keys
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const uint64_t rng_base = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq) * (uint64_t)a.Lk + (uint64_t)ki;
   const float scale2 = a.scale * LOG2E;
   const float* lse_g = a.lse + ((int64_t)n * a.heads + head) * a.Lq;
   const float* del_g = a.delta + ((int64_t)n * a.heads + head) * a.Lq;
-  Stage<D, TS> sq, so;
+  Stage<D, TS, NT> sq, so;
   sq.init(a.ldq);
   so.init(a.lddo);
 
@@ -523,20 +671,31 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv_kernel(const FaArgs a, cons
     }
     __syncthreads();
     sq.template store<RS>(smem + QR);
-    sq.template store<TR>(smem + QT);
-    so.template store<RS>(smem + OR_);
-    so.template store<TR>(smem + OT);
+    if constexpr (DO_K) {
+      sq.template store<TR>(smem + QT);
+      so.template store<RS>(smem + OR_);
+    }
+    if constexpr (DO_V) so.template store<TR>(smem + OT);
     if (threadIdx.x < 2 * TS) lse_s[threadIdx.x] = stat;
     __syncthreads();
 #pragma unroll
-    for (int qt = 0; qt < TS / 32; ++qt) {
+    for (int qt = 0; qt < KT; ++qt) {
       f32x16 st, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
 #pragma unroll
-      for (int s = 0; s < D / 16; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + QR, qt * 32, s), kf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + OR_, qt * 32, s), vf[s], dp, 0, 0, 0);
+      for (int s = 0; s < KSW; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + QR, qt * 32, split * KSW + s), kf[s], st, 0, 0, 0);
+        if constexpr (DO_K)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RS>(smem + OR_, qt * 32, split * KSW + s), vf[s], dp, 0, 0, 0);
+        if (DH > 128 && (s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the fragment prefetch depth (VGPR budget)
+      }
+      if constexpr (NS > 1) {
+        x_put(xbuf + ((kblk * 2 + 0) * NS + split) * XSLOT, st);
+        if constexpr (DO_K) x_put(xbuf + ((kblk * 2 + 1) * NS + split) * XSLOT, dp);
+        __syncthreads();
+        x_sum<NS>(xbuf + (kblk * 2 + 0) * NS * XSLOT, st);
+        if constexpr (DO_K) x_sum<NS>(xbuf + (kblk * 2 + 1) * NS * XSLOT, dp);
       }
       const int qrow0 = qt * 32;
 #pragma unroll
@@ -547,117 +706,253 @@ __global__ __launch_bounds__(256, 2) void fa_bwd_dkv_kernel(const FaArgs a, cons
         const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse_s[r])) : 0.f;
         float keep = 1.f;
         if (a.drop_p > 0.f) keep = rng_uniform(a.seed, rng_base + (uint64_t)query * (uint64_t)a.Lk) >= a.drop_p ? keep_scale : 0.f;
-        dp[e] = p * (dp[e] * keep - del_s[r]) * a.scale;  // dS
-        st[e] = p * keep;                                  // dropped P
+        if constexpr (DO_K) dp[e] = p * (dp[e] * keep - del_s[r]) * a.scale;  // dS
+        st[e] = p * keep;                                                      // dropped P
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = pack_acc(st, s2), df = pack_acc(dp, s2);
+        const bf16x8 pf = pack_acc(st, s2);
+        bf16x8 df;
+        if constexpr (DO_K) df = pack_acc(dp, s2);
 #pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<TR>(smem + OT, qt * 32 + 16 * s2, dt), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<TR>(smem + QT, qt * 32 + 16 * s2, dt), df, dk[dt], 0, 0, 0);
+        for (int dt = 0; dt < OB; ++dt) {
+          if constexpr (DO_V)
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<TR>(smem + OT, qt * 32 + 16 * s2, split * OB + dt), pf, dv[dt], 0, 0, 0);
+          if constexpr (DO_K)
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<TR>(smem + QT, qt * 32 + 16 * s2, split * OB + dt), df, dk[dt], 0, 0, 0);
+          if (DH > 128 && (dt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
   }
   if (ki < a.Lk) {
-    store_transposed<D>(dk, g.dk + (int64_t)n * a.sk + (int64_t)ki * a.ldk + head * D, half, 1.f);
-    store_transposed<D>(dv, g.dv + (int64_t)n * a.sv + (int64_t)ki * a.ldv + head * D, half, 1.f);
+    if constexpr (DO_K) store_transposed<DH>(dk, g.dk + (int64_t)n * a.sk + (int64_t)ki * a.ldk + head * D + split * DH, half, 1.f);
+    if constexpr (DO_V) store_transposed<DH>(dv, g.dv + (int64_t)n * a.sv + (int64_t)ki * a.ldv + head * D + split * DH, half, 1.f);
   }
 }
 
-template <int D, int TS>
-int launch_bwd(FaArgs a, const BwdOut& g, const bf16_t* out, hipStream_t s) {
-  const int64_t rows = (int64_t)(a.sdo / a.lddo) * 0 + 0;  // unused
-  (void)rows;
-  constexpr int RS = Geo<D>::ROW, TR = Geo<D>::TRS;
-  const size_t lds_dq = (size_t)TS * (2 * RS + TR);
-  const size_t lds_dkv = (size_t)TS * (2 * RS + 2 * TR) + 2 * TS * 4;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq_kernel<D, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv_kernel<D, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
-    attr = true;
-  }
-  // dQ: one workgroup per 128 queries; dK/dV: one per 128 keys
-  a.tiles = (a.Lq + 127) / 128;
-  a.nblk = a.tiles * a.heads * (int)(a.sdq);  // sdq carries N here (set by the caller)
-  hipLaunchKernelGGL((fa_bwd_dq_kernel<D, TS>), dim3(a.nblk), dim3(256), lds_dq, s, a, g);
-  a.tiles = (a.Lk + 127) / 128;
-  a.nblk = a.tiles * a.heads * (int)(a.sdq);
-  hipLaunchKernelGGL((fa_bwd_dkv_kernel<D, TS>), dim3(a.nblk), dim3(256), lds_dkv, s, a, g);
-  return case_check_launch("case_attention_bwd");
+// ---- launch helpers ---------------------------------------------------------------------------------------------------
+template <typename KernelT>
+void set_lds(KernelT kernel, size_t bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int D, int TS>
+// Geometry per head size: NS head-dim slices, NQ stationary blocks per workgroup, TS streamed rows per tile
+template <int D> struct Plan;
+template <> struct Plan<64> { static constexpr int NS = 1, NQ = 4, TS = 64, MINW = 2; };
+template <> struct Plan<96> { static constexpr int NS = 1, NQ = 4, TS = 64, MINW = 2; };
+template <> struct Plan<320> { static constexpr int NS = 2, NQ = 4, TS = 32, MINW = 2; };
+template <> struct Plan<480> { static constexpr int NS = 3, NQ = 2, TS = 32, MINW = 2; };
+
+template <int D>
+size_t fwd_lds() {
+  using P = Plan<D>;
+  return 2 * (size_t)(P::TS * Geo<D>::ROW + P::TS * Geo<D>::TRS) + (P::NS > 1 ? (size_t)P::NQ * P::NS * XSLOT * 4 : 0);
+}
+
+template <int D>
 int launch_fwd(const FaArgs& a, hipStream_t s) {
-  const size_t lds = 2 * (size_t)(TS * Geo<D>::ROW + TS * Geo<D>::TRS);
+  using P = Plan<D>;
+  const size_t lds = fwd_lds<D>();
+  auto kernel = &fa_fwd_kernel<D, P::NS, P::NQ, P::TS, P::MINW, false>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_kernel<D, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_lds(kernel, lds);
     attr = true;
   }
-  hipLaunchKernelGGL((fa_fwd_kernel<D, TS>), dim3(a.nblk), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kernel, dim3(a.nblk), dim3(64 * P::NS * P::NQ), lds, s, a);
   return case_check_launch("case_attention_fwd");
 }
 
+#include "attention_wide.inc"
+
+template <int D>
+int launch_fwd_splitkv(const FaArgs& a, hipStream_t s) {
+  using P = Plan<D>;
+  const size_t lds = fwd_lds<D>();
+  auto kernel = &fa_fwd_kernel<D, P::NS, P::NQ, P::TS, P::MINW, true>;
+  static bool attr = false;
+  if (!attr) {
+    set_lds(kernel, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(a.nblk), dim3(64 * P::NS * P::NQ), lds, s, a);
+  const int64_t rows = (int64_t)a.N * a.heads * a.Lq;
+  const int64_t threads = rows * (D / 8);
+  hipLaunchKernelGGL((fa_combine_kernel<D>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a.part_o, a.part_ml, a.o,
+                     a.lse, rows, a.ksplit, a.heads, a.Lq, a.ldo, a.so);
+  return case_check_launch("case_attention_fwd_splitkv");
+}
+
+template <int D>
+int launch_bwd(FaArgs a, const BwdOut& g, const bf16_t* out, float* delta, hipStream_t s) {
+  using P = Plan<D>;
+  constexpr int RS = Geo<D>::ROW, TR = Geo<D>::TRS, TS = P::TS, NS = P::NS, NQ = P::NQ, NT = 64 * NS * NQ;
+  const int64_t rows = (int64_t)a.N * a.Lq;
+  hipLaunchKernelGGL((fa_delta_kernel<D>), dim3((unsigned)((rows * a.heads + 255) / 256)), dim3(256), 0, s, a.dout, out, delta, rows,
+                     a.heads, a.Lq);
+  const size_t xb = NS > 1 ? (size_t)NQ * 2 * NS * XSLOT * 4 : 0;
+  const size_t lds_dq = (size_t)TS * (2 * RS + TR) + xb;
+  auto kdq = &fa_bwd_dq_kernel<D, NS, NQ, TS, P::MINW>;
+  static bool attr = false;
+  a.tiles = (a.Lq + 32 * NQ - 1) / (32 * NQ);
+  a.nblk = a.tiles * a.heads * a.N;
+  if constexpr (NS == 1) {
+    const size_t lds_dkv = (size_t)TS * (2 * RS + 2 * TR) + 2 * TS * 4;
+    auto kdkv = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 3>;
+    if (!attr) {
+      set_lds(kdq, lds_dq);
+      set_lds(kdkv, lds_dkv);
+      attr = true;
+    }
+    hipLaunchKernelGGL(kdq, dim3(a.nblk), dim3(NT), lds_dq, s, a, g);
+    a.tiles = (a.Lk + 32 * NQ - 1) / (32 * NQ);
+    a.nblk = a.tiles * a.heads * a.N;
+    hipLaunchKernelGGL(kdkv, dim3(a.nblk), dim3(NT), lds_dkv, s, a, g);
+  } else {
+    const size_t lds_dk = (size_t)TS * (2 * RS + TR) + 2 * TS * 4 + xb;
+    const size_t lds_dv = (size_t)TS * (RS + TR) + 2 * TS * 4 + xb;
+    auto kdk = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 1>;
+    auto kdv = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 2>;
+    if (!attr) {
+      set_lds(kdq, lds_dq);
+      set_lds(kdk, lds_dk);
+      set_lds(kdv, lds_dv);
+      attr = true;
+    }
+    hipLaunchKernelGGL(kdq, dim3(a.nblk), dim3(NT), lds_dq, s, a, g);
+    a.tiles = (a.Lk + 32 * NQ - 1) / (32 * NQ);
+    a.nblk = a.tiles * a.heads * a.N;
+    hipLaunchKernelGGL(kdk, dim3(a.nblk), dim3(NT), lds_dk, s, a, g);
+    hipLaunchKernelGGL(kdv, dim3(a.nblk), dim3(NT), lds_dv, s, a, g);
+  }
+  return case_check_launch("case_attention_bwd");
+}
+
+int fill_args(FaArgs& a, const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid) {
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv;
+  a.key_valid = key_valid;
+  a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.heads = (int)d->heads; a.N = (int)d->N; a.causal = d->causal;
+  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  return 0;
+}
+
+template <int D> int queries_per_wg() { return 32 * Plan<D>::NQ; }
+int queries_per_wg_of(int64_t d) {
+  return d == 64 ? queries_per_wg<64>() : d == 96 ? queries_per_wg<96>() : d == 320 ? queries_per_wg<320>() : queries_per_wg<480>();
+}
+int tile_rows_of(int64_t d) { return d == 64 ? Plan<64>::TS : d == 96 ? Plan<96>::TS : d == 320 ? Plan<320>::TS : Plan<480>::TS; }
+
 }  // namespace
 
-extern "C" int case_attention_supported(int64_t head_dim) { return head_dim == 64 || head_dim == 320; }
+#ifdef FAS_STAMPS
+static float* g_stamp_buf = nullptr;
+extern "C" int case_debug_stamp_buffer(void* p) { g_stamp_buf = (float*)p; return 0; }
+#endif
+
+extern "C" int case_attention_supported(int64_t head_dim) { return head_dim == 64 || head_dim == 96 || head_dim == 320 || head_dim == 480; }
+extern "C" int case_attention_bwd_supported(int64_t head_dim) { return case_attention_supported(head_dim); }
+
+#define CASE_ATTN_COMMON_CHECKS(NAME)                                                                                                     \
+  CASE_REQUIRE(d->N > 0 && d->heads > 0 && d->Lq > 0 && d->Lk > 0, NAME ": empty problem");                                               \
+  CASE_REQUIRE(case_attention_supported(d->head_dim), NAME ": head_dim %lld not built (64, 96, 320, 480)", (long long)d->head_dim);       \
+  CASE_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->sq % 8 == 0 && d->sk % 8 == 0 && d->sv % 8 == 0 &&            \
+                   (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0,                                           \
+               NAME ": operands must be 16-byte aligned with strides that are multiples of 8 elements");                                  \
+  CASE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, NAME ": drop_p out of range")
 
 extern "C" int case_attention_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                                   void* out, float* lse, case_stream_t stream) {
   CASE_REQUIRE(d && q && k && v && out && lse, "case_attention_fwd: null argument");
-  CASE_REQUIRE(d->N > 0 && d->heads > 0 && d->Lq > 0 && d->Lk > 0, "case_attention_fwd: empty problem");
-  CASE_REQUIRE(case_attention_supported(d->head_dim), "case_attention_fwd: head_dim %lld not built (64, 320)", (long long)d->head_dim);
-  CASE_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->sq % 8 == 0 && d->sk % 8 == 0 && d->sv % 8 == 0 &&
-                   (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 8 == 0 && d->ldo % 4 == 0,
-               "case_attention_fwd: operands must be 16-byte aligned with strides that are multiples of 8 elements");
-  CASE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "case_attention_fwd: drop_p out of range");
+  CASE_ATTN_COMMON_CHECKS("case_attention_fwd");
+  CASE_REQUIRE((uintptr_t)out % 8 == 0 && d->ldo % 4 == 0, "case_attention_fwd: out must be 8-byte aligned, ldo a multiple of 4");
   FaArgs a = {};
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
-  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv;
-  a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse; a.key_valid = key_valid;
-  a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.heads = (int)d->heads; a.causal = d->causal;
-  a.tiles = (a.Lq + 127) / 128;
+  fill_args(a, d, q, k, v, key_valid);
+  a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse;
+#ifdef FAS_STAMPS
+  a.part_ml = g_stamp_buf;
+#endif
+  const int qpw = queries_per_wg_of(d->head_dim);
+  a.tiles = (a.Lq + qpw - 1) / qpw;
   const int64_t nblk = (int64_t)a.tiles * d->heads * d->N;
   CASE_REQUIRE(nblk < (1ll << 31), "case_attention_fwd: grid too large");
   a.nblk = (int)nblk;
-  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
   hipStream_t s = (hipStream_t)stream;
-  if (d->head_dim == 64) return launch_fwd<64, 64>(a, s);
-  return launch_fwd<320, 32>(a, s);
+  switch (d->head_dim) {
+    case 64: return launch_fwd<64>(a, s);
+    case 96: return launch_fwd<96>(a, s);
+    case 320: return slab_fits<320>(a) ? launch_fwd_slab<320>(a, s) : launch_fwd<320>(a, s);   // both: 128 queries per workgroup
+    default: return launch_fwd<480>(a, s);
+  }
 }
 
-extern "C" int case_attention_bwd_supported(int64_t head_dim) { return head_dim == 64; }
+static int64_t splitkv_bytes(const CaseAttnDesc* d, int32_t ksplit) {
+  const int64_t rows = d->N * d->heads * d->Lq;
+  return (int64_t)ksplit * rows * (d->head_dim + 2) * 4;
+}
+
+extern "C" int case_attention_splitkv_workspace(const CaseAttnDesc* d, int32_t ksplit, int64_t* bytes) {
+  CASE_REQUIRE(d && bytes && ksplit >= 1, "case_attention_splitkv_workspace: bad argument");
+  *bytes = splitkv_bytes(d, ksplit);
+  return 0;
+}
+
+extern "C" int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                                          void* out, float* lse, void* workspace, int64_t workspace_bytes, int32_t ksplit,
+                                          case_stream_t stream) {
+  CASE_REQUIRE(d && q && k && v && out && lse && workspace, "case_attention_fwd_splitkv: null argument");
+  CASE_ATTN_COMMON_CHECKS("case_attention_fwd_splitkv");
+  CASE_REQUIRE((uintptr_t)out % 16 == 0 && d->ldo % 8 == 0 && d->so % 8 == 0, "case_attention_fwd_splitkv: out must be 16-byte aligned, strides multiples of 8");
+  CASE_REQUIRE(ksplit >= 1 && ksplit <= 256, "case_attention_fwd_splitkv: ksplit out of range");
+  CASE_REQUIRE(!d->causal, "case_attention_fwd_splitkv: causal attention has no long key axis on this path");
+  CASE_REQUIRE((uintptr_t)workspace % 16 == 0 && workspace_bytes >= splitkv_bytes(d, ksplit),
+               "case_attention_fwd_splitkv: workspace too small or misaligned (%lld bytes needed)", (long long)splitkv_bytes(d, ksplit));
+  FaArgs a = {};
+  fill_args(a, d, q, k, v, key_valid);
+  a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse;
+  const int ts = tile_rows_of(d->head_dim);
+  const int64_t tiles_k = (d->Lk + ts - 1) / ts;
+  a.kchunk = (int)((tiles_k + ksplit - 1) / ksplit) * ts;
+  a.ksplit = (int)((d->Lk + a.kchunk - 1) / a.kchunk);  // no empty chunks
+  const int64_t rows = d->N * d->heads * d->Lq;
+  a.part_o = (float*)workspace;
+  a.part_ml = a.part_o + (int64_t)a.ksplit * rows * d->head_dim;
+  const int qpw = queries_per_wg_of(d->head_dim);
+  a.tiles = (a.Lq + qpw - 1) / qpw;
+  const int64_t nblk = (int64_t)a.tiles * d->heads * d->N * a.ksplit;
+  CASE_REQUIRE(nblk < (1ll << 31), "case_attention_fwd_splitkv: grid too large");
+  a.nblk = (int)nblk;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->head_dim) {
+    case 64: return launch_fwd_splitkv<64>(a, s);
+    case 96: return launch_fwd_splitkv<96>(a, s);
+    case 320: return launch_fwd_splitkv<320>(a, s);
+    default: return launch_fwd_splitkv<480>(a, s);
+  }
+}
 
 extern "C" int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                                   const void* out, const float* lse, const void* dout, float* delta, void* dq, void* dk, void* dv,
                                   case_stream_t stream) {
   CASE_REQUIRE(d && q && k && v && out && lse && dout && delta && dq && dk && dv, "case_attention_bwd: null argument");
-  CASE_REQUIRE(d->N > 0 && d->heads > 0 && d->Lq > 0 && d->Lk > 0, "case_attention_bwd: empty problem");
-  CASE_REQUIRE(case_attention_bwd_supported(d->head_dim), "case_attention_bwd: head_dim %lld not built (64)", (long long)d->head_dim);
-  CASE_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->sq % 8 == 0 && d->sk % 8 == 0 && d->sv % 8 == 0 &&
-                   d->ldo % 8 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
-                   (uintptr_t)out % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 8 == 0 && (uintptr_t)dk % 8 == 0 &&
+  CASE_ATTN_COMMON_CHECKS("case_attention_bwd");
+  CASE_REQUIRE(d->ldo % 8 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dq % 8 == 0 && (uintptr_t)dk % 8 == 0 &&
                    (uintptr_t)dv % 8 == 0,
                "case_attention_bwd: operands must be 16-byte aligned with strides that are multiples of 8 elements");
   CASE_REQUIRE(d->ldo == d->heads * d->head_dim && d->so == d->Lq * d->ldo, "case_attention_bwd: out / dout must be contiguous [N, Lq, heads*head_dim]");
   FaArgs a = {};
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
-  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv;
-  a.lse = const_cast<float*>(lse); a.key_valid = key_valid;
+  fill_args(a, d, q, k, v, key_valid);
+  a.lse = const_cast<float*>(lse);
   a.dout = (const bf16_t*)dout; a.lddo = d->ldo; a.sdo = d->so; a.delta = delta;
-  a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.heads = (int)d->heads; a.causal = d->causal;
-  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
-  a.sdq = d->N;  // launch_bwd reads N from here
-  const int64_t blocks = ((int64_t)((d->Lq > d->Lk ? d->Lq : d->Lk) + 127) / 128) * d->heads * d->N;
+  const int64_t blocks = ((int64_t)((d->Lq > d->Lk ? d->Lq : d->Lk) + 31) / 32) * d->heads * d->N;
   CASE_REQUIRE(blocks < (1ll << 31), "case_attention_bwd: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  const int64_t rows = d->N * d->Lq;
-  hipLaunchKernelGGL((fa_delta_kernel<64>), dim3((unsigned)((rows * d->heads + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dout,
-                     (const bf16_t*)out, delta, rows, (int)d->heads, (int)d->Lq);
   BwdOut g = {(bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv};
-  return launch_bwd<64, 64>(a, g, (const bf16_t*)out, s);
+  switch (d->head_dim) {
+    case 64: return launch_bwd<64>(a, g, (const bf16_t*)out, delta, s);
+    case 96: return launch_bwd<96>(a, g, (const bf16_t*)out, delta, s);
+    case 320: return launch_bwd<320>(a, g, (const bf16_t*)out, delta, s);
+    default: return launch_bwd<480>(a, g, (const bf16_t*)out, delta, s);
+  }
 }

@@ -520,22 +520,36 @@ def _src_key(t):
 
 
 # Which attention path runs:
-#   "auto"    fused kernels for head sizes with a fused forward AND backward; everything else GEMM + softmax + GEMM (the
-#             unfused forward leaves the probabilities behind for the backward, which otherwise recomputes them)
-#   "fused"   the fused forward wherever one is built, even without a fused backward (the backward then recomputes P)
+#   "auto"    per head size, whichever measured faster on MI355X (tools/attn_bench.py, profiles/r02_attn_bench.jsonl):
+#             head_dim 64 / 96 fused forward + backward; head_dim 320 / 480 (the 5H blocks) fused forward only when no
+#             backward will follow (their fused backward recomputes S in three kernels and is slower than four batched GEMMs
+#             over saved probabilities), otherwise GEMM + softmax + GEMM
+#   "fused"   the fused kernels wherever they are built (64, 96, 320, 480: forward and backward)
 #   "unfused" never fused (tests run the production-shape fixtures under both)
 ATTENTION_MODE = "auto"
+_FUSED_TRAINING = (64, 96)
+_FUSED_INFERENCE = (64, 96, 320)
 
 
-def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d):
+def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, needs_grad=True):
     if ATTENTION_MODE == "unfused" or q_src.dtype != torch.bfloat16 or not A.lib.case_attention_supported(d):
         return False
-    if ATTENTION_MODE != "fused" and not A.lib.case_attention_bwd_supported(d):
-        return False
+    if ATTENTION_MODE == "auto":
+        if d not in (_FUSED_TRAINING if needs_grad else _FUSED_INFERENCE):
+            return False
     for t, off in ((q_src, q_off), (k_src, k_off), (v_src, v_off)):
         if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:
             return False
     return True
+
+
+def _kv_splits(N, heads, Lq, Lk, causal):
+    """Key chunks for the split-KV forward: only when the plain launch would leave most of the 256 CUs idle (few sequences x
+    heads x query tiles) and the memory is long enough to cut into chunks of >= 1024 keys."""
+    wgs = N * heads * ((Lq + 127) // 128)
+    if causal or wgs >= 192 or Lk < 2048:
+        return 1
+    return max(1, min(Lk // 1024, (512 + wgs - 1) // wgs, 64))
 
 
 def _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop):
@@ -562,12 +576,21 @@ class AttentionFn(Function):
         alpha = 1.0 / math.sqrt(d)
         drop = (p_drop,) + config.next_rng(N * heads * Lq * Lk) if p_drop > 0.0 else None
         O = torch.empty(N, Lq, E, dtype=dt, device=dev)
-        fused = _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d)
+        fused = _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, any(ctx.needs_input_grad[:3]))
         if fused:
             lse = torch.empty(N, heads, Lq, dtype=torch.float32, device=dev)
             ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)
-            A.call("case_attention_fwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O),
-                   _ptr(lse), _stream())
+            ksplit = _kv_splits(N, heads, Lq, Lk, causal)
+            if ksplit > 1:
+                # long memory, few (sequence, head) pairs: cut the key range over workgroups (flash-decoding style merge)
+                need = A.i64(0)
+                A.call("case_attention_splitkv_workspace", ad, ksplit, need)
+                ws = torch.empty(need.value // 4, dtype=torch.float32, device=dev)
+                A.call("case_attention_fwd_splitkv", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid),
+                       _ptr(O), _ptr(lse), _ptr(ws), need.value, ksplit, _stream())
+            else:
+                A.call("case_attention_fwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O),
+                       _ptr(lse), _stream())
             ctx.save_for_backward(q_src, k_src, v_src, key_valid, O, lse)
         else:
             S, Pd = AttentionFn._probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha)

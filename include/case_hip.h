@@ -161,8 +161,12 @@ int case_softmax_bwd(const CaseSoftmaxDesc* d, const void* dy, const void* p, vo
  * Dropout acts on the probabilities with the same counter RNG / element index as case_softmax_fwd on [N, heads, Lq, Lk].
  * Backward: delta f32 [N, heads, Lq] is scratch (rowsum(dO * O), written by the call); dq / dk / dv are bf16 slices of
  * the gradient of the packed projections, addressed with the same strides as q / k / v.
- * case_attention_supported(head_dim) != 0 tells whether a head size is built (forward: 64, 320; backward: 64 -- see
- * case_attention_bwd_supported); other sizes use the unfused GEMM + softmax path.
+ * case_attention_supported(head_dim) != 0 tells whether a head size is built (64, 96, 320 = 5 x 512 / 8, 480 = 5 x 768 / 8,
+ * forward and backward -- case_attention_bwd_supported); other sizes use the unfused GEMM + softmax path.  Head sizes above
+ * 128 split the head dim over 2-3 waves per block of 32 rows (partial score tiles are exchanged through LDS).
+ * case_attention_fwd_splitkv: same result for long memories with few (sequence, head) pairs (cfg 5 cross-attention: 40
+ * queries x 20 480 keys): the keys are cut into `ksplit` chunks handled by different workgroups, whose unnormalised partials
+ * go through the caller-owned `workspace` (size from case_attention_splitkv_workspace) and a merge kernel.  Not causal.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t N, heads, Lq, Lk, head_dim;
@@ -176,6 +180,10 @@ typedef struct {
 int case_attention_supported(int64_t head_dim);
 int case_attention_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                        void* out, float* lse, case_stream_t stream);
+int case_attention_splitkv_workspace(const CaseAttnDesc* d, int32_t ksplit, int64_t* bytes);
+int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                               void* out, float* lse, void* workspace, int64_t workspace_bytes, int32_t ksplit,
+                               case_stream_t stream);
 int case_attention_bwd_supported(int64_t head_dim);
 int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                        const void* out, const float* lse, const void* dout, float* delta, void* dq, void* dk, void* dv,
