@@ -209,16 +209,18 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.69314718055994531f;
 // The softmax runs in the base-2 domain: scores are scaled by scale * log2(e) once, every exponential is a bare v_exp_f32.
 constexpr float RESCALE_THR = 8.f * LOG2E;
 
-// Uniforms of four consecutive counters (the four keys one accumulator register group of a lane covers): two hashes when
-// the first counter is even (element pairs share a hash, common.h), four otherwise.
-__device__ __forceinline__ void rng4(uint64_t seed, uint64_t i0, float (&u)[4]) {
-  if ((i0 & 1) == 0) {
-    rng_uniform2(seed, i0, u[0], u[1]);
-    rng_uniform2(seed, i0 + 2, u[2], u[3]);
-  } else {
+// Dropout of one 32x32 accumulator tile in the query-stationary kernels (lane = one row of the probability matrix, its 16
+// registers = columns col0 + 8 g + 4 half + {0..3}): 8 pair hashes per tile and lane (common.h: attention dropout).
+__device__ __forceinline__ void drop_tile_rows(f32x16& x, uint32_t row_key, uint32_t col0, int half, uint32_t thr, float scale) {
+  const uint32_t base = ((col0 >> 1) + 2u * (uint32_t)half) * RNG_C1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = rng_uniform(seed, i0 + k);
-  }
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t bits = rng_pair_bits_pre(row_key, base + (uint32_t)(4 * g + i) * RNG_C1);
+      x[4 * g + 2 * i] = (bits & 0xffffu) >= thr ? x[4 * g + 2 * i] * scale : 0.f;
+      x[4 * g + 2 * i + 1] = (bits >> 16) >= thr ? x[4 * g + 2 * i + 1] * scale : 0.f;
+    }
 }
 
 // streamed row index of accumulator register e in a 32-row tile
@@ -306,7 +308,8 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs
   __syncthreads();
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const float scale2 = a.scale * LOG2E;
-  const uint64_t rng_row = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi) * (uint64_t)a.Lk;
+  const uint32_t thr = rng_threshold(a.drop_p);
+  const uint32_t row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi));
   FAS_STAMP(1);
 
   for (int t = 0; t < ntiles; ++t) {
@@ -334,26 +337,22 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs
         __syncthreads();
         x_sum<NS>(xbuf + qb * NS * XSLOT, st);
       }
-      // ---- mask + online softmax (per lane = per query)
+      // ---- mask + online softmax (per lane = per query); scores stay unscaled, the scale rides in the exponent's FMA
       const int key0 = key_begin + t * TS + kt * 32;
-      float mx = -INFINITY;
       // interior tile: every key valid and (causal) not beyond the wave's first query -> no per-element mask work
       const bool all_ok = ((mask >> (32 * kt)) & 0xffffffffull) == 0xffffffffull && (!a.causal || key0 + 31 <= q0);
-      if (all_ok) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          st[e] *= scale2;
-          mx = fmaxf(mx, st[e]);
-        }
-      } else {
+      if (!all_ok) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = key0 + acc_row(e, half);
           const bool ok = ((mrow >> ((e & 3) + 8 * (e >> 2) + 32 * kt)) & 1ull) && (!a.causal || key <= qi);
-          st[e] = ok ? st[e] * scale2 : -INFINITY;
-          mx = fmaxf(mx, st[e]);
+          st[e] = ok ? st[e] : -INFINITY;
         }
       }
+      float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, st[e]), st[e + 1]);
+      mx = fmaxf(mx, st[15]) * scale2;  // scale2 > 0: the maximum commutes with the scaling
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // lazy rescale: the running reference max moves only when some query's tile max exceeds it by more than THR;
       // probabilities then stay below e^THR (fine for the bf16 P operand, l and O accumulate in f32), and the
@@ -370,23 +369,15 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs
           for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
         }
       }
+      const float mref = (m == -INFINITY) ? 0.f : m;  // nothing unmasked yet: st = -inf -> p = 0 whatever the reference
       float ps = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[e] - m);
-        ps += p;
-        st[e] = p;
+        st[e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -mref));
+        ps += st[e];
       }
       lsum += ps;
-      if (a.drop_p > 0.f) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          float u[4];
-          rng4(a.seed, rng_row + (uint64_t)(key0 + 8 * gq + 4 * half), u);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) st[4 * gq + k] = u[k] >= a.drop_p ? st[4 * gq + k] * keep_scale : 0.f;
-        }
-      }
+      if (a.drop_p > 0.f) drop_tile_rows(st, row_key, (uint32_t)key0, half, thr, keep_scale);
       // ---- O^T += V^T P^T  (this wave's head-dim slice)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -538,7 +529,8 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaA
   int ntiles = (a.Lk + TS - 1) / TS;
   if (a.causal) ntiles = min(ntiles, (min(a.Lq, qt * (32 * NQ) + 32 * NQ) - 1) / TS + 1);
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-  const uint64_t rng_row = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi) * (uint64_t)a.Lk;
+  const uint32_t thr = rng_threshold(a.drop_p);
+  const uint32_t row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi));
   Stage<D, TS, NT> sk, sv;
   RowMask rm;
   sk.init(a.ldk);
@@ -573,29 +565,19 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaA
         x_sum<NS>(xbuf + (qb * 2 + 1) * NS * XSLOT, dp);
       }
       const int key0 = t * TS + kt * 32;
-      if (a.drop_p > 0.f) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          float u[4];
-          rng4(a.seed, rng_row + (uint64_t)(key0 + 8 * gq + 4 * half), u);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) dp[4 * gq + k] = u[k] >= a.drop_p ? dp[4 * gq + k] * keep_scale : 0.f;
-        }
-      }
+      if (a.drop_p > 0.f) drop_tile_rows(dp, row_key, (uint32_t)key0, half, thr, keep_scale);
       const bool all_ok = ((mrow_all >> (32 * kt)) & 0xffffffffull) == 0xffffffffull && (!a.causal || key0 + 31 <= q0);
+      // dS^T / scale = P^T (dP^T - delta): the factor `scale` is applied once to the finished dQ
       if (all_ok) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse2_q));
-          st[e] = p * (dp[e] - delta_q) * a.scale;  // dS^T
-        }
+        for (int e = 0; e < 16; ++e) st[e] = __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse2_q)) * (dp[e] - delta_q);
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = key0 + acc_row(e, half);
           const bool ok = ((mrow >> ((e & 3) + 8 * (e >> 2) + 32 * kt)) & 1ull) && (!a.causal || key <= qi);
           const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse2_q)) : 0.f;
-          st[e] = p * (dp[e] - delta_q) * a.scale;  // dS^T
+          st[e] = p * (dp[e] - delta_q);
         }
       }
 #pragma unroll
@@ -609,7 +591,7 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaA
       }
     }
   }
-  if (qi < a.Lq) store_transposed<DH>(acc, g.dq + (int64_t)n * a.sq + (int64_t)qi * a.ldq + head * D + split * DH, half, 1.f);
+  if (qi < a.Lq) store_transposed<DH>(acc, g.dq + (int64_t)n * a.sq + (int64_t)qi * a.ldq + head * D + split * DH, half, a.scale);
 }
 
 // ---- dK / dV: stationary keys (lane = key); streams Q and dO.  WHAT: 3 = both (NS = 1), 1 = dK only, 2 = dV only -------
@@ -621,10 +603,11 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
   constexpr int RS = Geo<D>::ROW, TR = Geo<D>::TRS;
   // images: Q rows (S) always; Q transposed (dK); dO rows (dP, for dK); dO transposed (dV)
   constexpr int QR = 0, QT = TS * RS, OR_ = QT + (DO_K ? TS * TR : 0), OT = OR_ + (DO_K ? TS * RS : 0);
-  constexpr int ST = OT + (DO_V ? TS * TR : 0), XB = ST + 2 * TS * 4;
+  constexpr int ST = OT + (DO_V ? TS * TR : 0), XB = ST + 3 * TS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* lse_s = reinterpret_cast<float*>(smem + ST);
+  float* lse_s = reinterpret_cast<float*>(smem + ST);   // per streamed query: lse (base 2), delta, dropout row key
   float* del_s = lse_s + TS;
+  uint32_t* rk_s = reinterpret_cast<uint32_t*>(del_s + TS);
   float* xbuf = reinterpret_cast<float*>(smem + XB);
   const int pid = xcd_remap(blockIdx.x, a.nblk);
   const int ktile = pid % a.tiles, head = (pid / a.tiles) % a.heads, n = pid / (a.tiles * a.heads);
@@ -636,6 +619,7 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
   const bf16_t* V = a.v + (int64_t)n * a.sv + head * D;
   const bf16_t* DO = a.dout + (int64_t)n * a.sdo + head * D;
   const bool key_ok = ki < a.Lk && (!a.key_valid || a.key_valid[(int64_t)n * a.Lk + ki]);
+  const bool key_ok_all = __all(key_ok);  // every key of this wave's block is real: interior tiles skip the per-element masks
 
   bf16x8 kf[KSW], vf[DO_K ? KSW : 1];
   load_stationary<DH>(kf, K + split * DH, a.ldk, k0, a.Lk);
@@ -653,7 +637,9 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
   const int ntiles = (a.Lq + TS - 1) / TS;
   const int tbegin = a.causal ? (ktile * (32 * NQ)) / TS : 0;  // queries before the first key of this workgroup see none of its keys
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-  const uint64_t rng_base = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq) * (uint64_t)a.Lk + (uint64_t)ki;
+  const uint32_t thr = rng_threshold(a.drop_p);
+  const uint64_t rng_row0 = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq);
+  const uint32_t jc1 = ((uint32_t)ki >> 1) * RNG_C1, field_shift = 16u * ((uint32_t)ki & 1u);  // this lane's column of the P matrix
   const float scale2 = a.scale * LOG2E;
   const float* lse_g = a.lse + ((int64_t)n * a.heads + head) * a.Lq;
   const float* del_g = a.delta + ((int64_t)n * a.heads + head) * a.Lq;
@@ -668,6 +654,8 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
     if (threadIdx.x < 2 * TS) {
       const int r = t * TS + (threadIdx.x % TS);
       stat = threadIdx.x < TS ? (r < a.Lq ? lse_g[r] * LOG2E : INFINITY) : (r < a.Lq ? del_g[r] : 0.f);  // lse = +inf -> p = 0
+    } else if (threadIdx.x < 3 * TS && a.drop_p > 0.f) {
+      stat = __uint_as_float(rng_row_key(a.seed, rng_row0 + (uint64_t)(t * TS + (threadIdx.x - 2 * TS))));
     }
     __syncthreads();
     sq.template store<RS>(smem + QR);
@@ -676,7 +664,7 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
       so.template store<RS>(smem + OR_);
     }
     if constexpr (DO_V) so.template store<TR>(smem + OT);
-    if (threadIdx.x < 2 * TS) lse_s[threadIdx.x] = stat;
+    if (threadIdx.x < 3 * TS) lse_s[threadIdx.x] = stat;
     __syncthreads();
 #pragma unroll
     for (int qt = 0; qt < KT; ++qt) {
@@ -697,17 +685,29 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
         x_sum<NS>(xbuf + (kblk * 2 + 0) * NS * XSLOT, st);
         if constexpr (DO_K) x_sum<NS>(xbuf + (kblk * 2 + 1) * NS * XSLOT, dp);
       }
-      const int qrow0 = qt * 32;
+      // per-query constants of this lane's 16 accumulator rows (queries 8 g + 4 half + {0..3} of the tile): four 16-byte reads each
+      const int qrow0 = qt * 32 + 4 * half;
+      const bool interior = key_ok_all && (!a.causal || k0 + 31 <= t * TS + qt * 32);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = qrow0 + acc_row(e, half);
-        const int query = t * TS + r;
-        const bool ok = key_ok && (!a.causal || ki <= query);
-        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse_s[r])) : 0.f;
-        float keep = 1.f;
-        if (a.drop_p > 0.f) keep = rng_uniform(a.seed, rng_base + (uint64_t)query * (uint64_t)a.Lk) >= a.drop_p ? keep_scale : 0.f;
-        if constexpr (DO_K) dp[e] = p * (dp[e] * keep - del_s[r]) * a.scale;  // dS
-        st[e] = p * keep;                                                      // dropped P
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + qrow0 + 8 * gq);
+        f32x4 del4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (DO_K) del4 = *reinterpret_cast<const f32x4*>(del_s + qrow0 + 8 * gq);
+        u32x4 rk4 = {0u, 0u, 0u, 0u};
+        if (a.drop_p > 0.f) rk4 = *reinterpret_cast<const u32x4*>(rk_s + qrow0 + 8 * gq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 4 * gq + i;
+          float p = __builtin_amdgcn_exp2f(fmaf(st[e], scale2, -lse4[i]));
+          if (!interior) {
+            const int query = t * TS + qrow0 + 8 * gq + i;
+            p = (key_ok && (!a.causal || ki <= query)) ? p : 0.f;
+          }
+          float keep = 1.f;
+          if (a.drop_p > 0.f) keep = ((rng_pair_bits_pre(rk4[i], jc1) >> field_shift) & 0xffffu) >= thr ? keep_scale : 0.f;
+          if constexpr (DO_K) dp[e] = p * (dp[e] * keep - del4[i]);  // dS / scale (the factor is applied to the finished dK)
+          st[e] = p * keep;                                            // dropped P
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
     }
   }
   if (ki < a.Lk) {
-    if constexpr (DO_K) store_transposed<DH>(dk, g.dk + (int64_t)n * a.sk + (int64_t)ki * a.ldk + head * D + split * DH, half, 1.f);
+    if constexpr (DO_K) store_transposed<DH>(dk, g.dk + (int64_t)n * a.sk + (int64_t)ki * a.ldk + head * D + split * DH, half, a.scale);
     if constexpr (DO_V) store_transposed<DH>(dv, g.dv + (int64_t)n * a.sv + (int64_t)ki * a.ldv + head * D + split * DH, half, 1.f);
   }
 }
@@ -798,7 +798,7 @@ int launch_bwd(FaArgs a, const BwdOut& g, const bf16_t* out, float* delta, hipSt
   a.tiles = (a.Lq + 32 * NQ - 1) / (32 * NQ);
   a.nblk = a.tiles * a.heads * a.N;
   if constexpr (NS == 1) {
-    const size_t lds_dkv = (size_t)TS * (2 * RS + 2 * TR) + 2 * TS * 4;
+    const size_t lds_dkv = (size_t)TS * (2 * RS + 2 * TR) + 3 * TS * 4;
     auto kdkv = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 3>;
     if (!attr) {
       set_lds(kdq, lds_dq);
@@ -810,8 +810,8 @@ int launch_bwd(FaArgs a, const BwdOut& g, const bf16_t* out, float* delta, hipSt
     a.nblk = a.tiles * a.heads * a.N;
     hipLaunchKernelGGL(kdkv, dim3(a.nblk), dim3(NT), lds_dkv, s, a, g);
   } else {
-    const size_t lds_dk = (size_t)TS * (2 * RS + TR) + 2 * TS * 4 + xb;
-    const size_t lds_dv = (size_t)TS * (RS + TR) + 2 * TS * 4 + xb;
+    const size_t lds_dk = (size_t)TS * (2 * RS + TR) + 3 * TS * 4 + xb;
+    const size_t lds_dv = (size_t)TS * (RS + TR) + 3 * TS * 4 + xb;
     auto kdk = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 1>;
     auto kdv = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 2>;
     if (!attr) {

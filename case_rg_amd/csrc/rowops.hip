@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const CaseSoftmaxDesc 
   const int sub = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int64_t total = d.outer * d.inner * d.R;
   const float keep_scale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+  const uint32_t thr = rng_threshold(d.drop_p);
   for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < total; base += (int64_t)gridDim.x * rows_per_block) {
     const int64_t row = base + sub;
     const bool live = row < total;  // keep every wave in the block-level reductions
@@ -342,14 +343,12 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const CaseSoftmaxDesc 
     s = row_sum<TPR>(s, red);
     if (!live) continue;
     const float inv = s > 0.f ? 1.f / s : 0.f;
+    const uint32_t rkey = d.drop_p > 0.f ? rng_row_key(d.seed, d.offset + (uint64_t)rr) : 0u;
     for (int64_t c = t; c < d.C; c += TPR) {
       float p = 0.f;
       if (row_ok && c < cmax && (!cv || cv[c]) && inv > 0.f) p = expf(Elem<TI>::ld(xr + c) - m) * inv;
       Elem<TO>::st(p_out + rr * d.C + c, p);
-      if (d.drop_p > 0.f) {
-        const float u = rng_uniform(d.seed, d.offset + (uint64_t)(rr * d.C + c));
-        Elem<TO>::st(y_out + rr * d.C + c, u >= d.drop_p ? p * keep_scale : 0.f);
-      }
+      if (d.drop_p > 0.f) Elem<TO>::st(y_out + rr * d.C + c, attn_keep(rkey, (uint32_t)c, thr) ? p * keep_scale : 0.f);
     }
   }
 }
@@ -362,22 +361,24 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const CaseSoftmaxDesc 
   const int sub = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int64_t total = d.outer * d.inner * d.R;
   const float keep_scale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+  const uint32_t thr = rng_threshold(d.drop_p);
   for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < total; base += (int64_t)gridDim.x * rows_per_block) {
     const int64_t row = base + sub;
     const bool live = row < total;
     const int64_t rr = live ? row : 0;
+    const uint32_t rkey = d.drop_p > 0.f ? rng_row_key(d.seed, d.offset + (uint64_t)rr) : 0u;
     float dot = 0.f;
     if (live)
       for (int64_t c = t; c < d.C; c += TPR) {
         float g = Elem<TO>::ld(dy + rr * d.C + c);
-        if (d.drop_p > 0.f) g = rng_uniform(d.seed, d.offset + (uint64_t)(rr * d.C + c)) >= d.drop_p ? g * keep_scale : 0.f;
+        if (d.drop_p > 0.f) g = attn_keep(rkey, (uint32_t)c, thr) ? g * keep_scale : 0.f;
         dot += g * Elem<TO>::ld(p + rr * d.C + c);
       }
     dot = row_sum<TPR>(dot, red);
     if (!live) continue;
     for (int64_t c = t; c < d.C; c += TPR) {
       float g = Elem<TO>::ld(dy + rr * d.C + c);
-      if (d.drop_p > 0.f) g = rng_uniform(d.seed, d.offset + (uint64_t)(rr * d.C + c)) >= d.drop_p ? g * keep_scale : 0.f;
+      if (d.drop_p > 0.f) g = attn_keep(rkey, (uint32_t)c, thr) ? g * keep_scale : 0.f;
       const float pv = Elem<TO>::ld(p + rr * d.C + c);
       Elem<TI>::st(dx + rr * d.C + c, pv * (g - dot));
     }
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const CaseSoftmaxD
       for (int e = 0; e < 8; ++e) v[j][e] *= inv;
       Vec16<bf16_t>::store(p_out + row * d.C + c0, v[j]);
       if (d.drop_p > 0.f) {
-        dropout8(v[j], d.seed, d.offset + (uint64_t)(row * d.C + c0), d.drop_p, keep_scale);
+        attn_dropout8(v[j], rng_row_key(d.seed, d.offset + (uint64_t)row), (uint32_t)c0, rng_threshold(d.drop_p), keep_scale);
         Vec16<bf16_t>::store(y_out + row * d.C + c0, v[j]);
       }
     }
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const CaseSoftmaxD
       if (c0 < d.C) {
         Vec16<bf16_t>::load(dy + row * d.C + c0, g[j]);
         Vec16<bf16_t>::load(p + row * d.C + c0, pv[j]);
-        if (d.drop_p > 0.f) dropout8(g[j], d.seed, d.offset + (uint64_t)(row * d.C + c0), d.drop_p, keep_scale);
+        if (d.drop_p > 0.f) attn_dropout8(g[j], rng_row_key(d.seed, d.offset + (uint64_t)row), (uint32_t)c0, rng_threshold(d.drop_p), keep_scale);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dot += g[j][e] * pv[j][e];
       }
