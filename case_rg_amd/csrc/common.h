@@ -41,6 +41,9 @@ template <> struct Elem<bf16_t> {
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
   static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+  }
   static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -51,8 +54,7 @@ template <> struct Vec16<float> {
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
-  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
+  static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -60,6 +62,7 @@ template <> struct Vec16<bf16_t> {
       v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
   }
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll

@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
   }
 }
 
+// Backward for row widths that are not whole 64-lane chunks (768, 3840 ... of cfg 5): the guarded form (one row in flight per
+// wave, per-lane column partials in registers).  Slower than the two kernels below; kept for generality.
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_vec_guarded_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ x2, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          T* __restrict__ dx, const T* __restrict__ dx_add,
@@ -266,6 +268,235 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
   }
 }
 
+// Backward.  One wave per row, the row in registers; the raw 16-byte vectors of the wave's NEXT row (x, dy and the optional
+// x2 / dx_add streams) are requested before the current row's reductions, so every wave keeps two rows of loads in flight:
+// the row is a dependent chain (load -> two wave reductions -> store) and with one row in flight per wave the kernel ran at
+// 1.4-1.7 TB/s on streams that do not fit the Infinity Cache (copy ceiling 6.3 TB/s).  The loop body is branch-free (cols ==
+// NV * 64 * E, optional streams are template flags): behind a conditional load hipcc waits vmcnt(0) and drains the prefetch.
+template <typename T, int NV, bool HAS_X2, bool HAS_ADD>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ x2, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         T* __restrict__ dx, const T* __restrict__ dx_add,
+                                                         float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
+                                                         int64_t cols) {
+  constexpr int E = Vec16<T>::N;
+  extern __shared__ float part[];  // [4 waves][2][cols] column partials, summed and added to d_gamma / d_beta at the end
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wid, nwaves = (int64_t)gridDim.x * 4;
+  float ag[NV][E], ab[NV][E], g[NV][E];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = ((int64_t)i * 64 + lane) * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      ag[i][e] = ab[i][e] = 0.f;
+      g[i][e] = gamma[c + e];
+    }
+  }
+  struct Raw {  // a row stays packed (16 bytes per stream and chunk) between the two passes
+    uint4 x[NV], d[NV], x2[HAS_X2 ? NV : 1], add[HAS_ADD ? NV : 1];
+    float mu, rs;
+  };
+  auto request = [&](Raw& w, int64_t r) {
+    const int64_t base = r * cols + (int64_t)lane * E;
+    w.mu = mean[r];
+    w.rs = rstd[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t o = base + (int64_t)i * 64 * E;
+      w.x[i] = *reinterpret_cast<const uint4*>(x + o);
+      w.d[i] = *reinterpret_cast<const uint4*>(dy + o);
+      if constexpr (HAS_X2) w.x2[i] = *reinterpret_cast<const uint4*>(x2 + o);
+      if constexpr (HAS_ADD) w.add[i] = *reinterpret_cast<const uint4*>(dx_add + o);
+    }
+  };
+  auto normalised = [&](const Raw& w, int i, float (&xh)[E]) {
+    Vec16<T>::unpack(w.x[i], xh);
+    if constexpr (HAS_X2) {
+      float t[E];
+      Vec16<T>::unpack(w.x2[i], t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) xh[e] += t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) xh[e] = (xh[e] - w.mu) * w.rs;
+  };
+  Raw cur, nxt;
+  request(cur, wave < rows ? wave : rows - 1);
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    request(nxt, r + nwaves < rows ? r + nwaves : rows - 1);  // unconditional: the last one re-reads a row and is dropped
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float xh[E], d[E];
+      normalised(cur, i, xh);
+      Vec16<T>::unpack(cur.d[i], d);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float gy = d[e] * g[i][e];
+        s1 += gy;
+        s2 += gy * xh[e];
+        ag[i][e] += d[e] * xh[e];
+        ab[i][e] += d[e];
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)cols, m2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float xh[E], d[E], o[E];
+      normalised(cur, i, xh);
+      Vec16<T>::unpack(cur.d[i], d);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = cur.rs * (d[e] * g[i][e] - m1 - xh[e] * m2);
+      if constexpr (HAS_ADD) {  // a second gradient of the same tensor (its residual use), summed here instead of by a separate pass
+        float w[E];
+        Vec16<T>::unpack(cur.add[i], w);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] += w[e];
+      }
+      Vec16<T>::store(dx + r * cols + ((int64_t)i * 64 + lane) * E, o);
+    }
+    cur = nxt;
+  }
+  // column partials: every wave parks its sums in LDS, then thread t adds columns t, t + 256, ... -- 256 contiguous bytes per
+  // atomic wave-instruction (a lane adding its own 8 columns is a 32-byte-strided scatter: one line per lane)
+  float* mine = part + (int64_t)wid * 2 * cols;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = ((int64_t)i * 64 + lane) * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      mine[c + e] = ag[i][e];
+      mine[cols + c + e] = ab[i][e];
+    }
+  }
+  __syncthreads();
+  for (int64_t c = threadIdx.x; c < 2 * cols; c += 256) {
+    const float t = part[c] + part[2 * cols + c] + part[4 * cols + c] + part[6 * cols + c];
+    atomicAdd(c < cols ? d_gamma + c : d_beta + (c - cols), t);
+  }
+}
+
+// Backward for WIDE rows (5H = 2560 columns: the first TransformerBlock of every stack).  With a whole row per wave the
+// per-lane gamma / beta partial sums alone take 2 x 40 registers next to two passes' worth of row data: 250+ registers, one
+// wave per SIMD, 1.7 TB/s.  Here a workgroup of NW waves shares each row: wave w owns columns [512 w, 512 w + 512) (8 per
+// lane), the two row statistics are combined through LDS (R rows per barrier, slots double-buffered -> one barrier per
+// group), and the loads of the next group are requested before the barrier.  ~70 registers, 4+ workgroups per CU.
+template <typename T, int R, bool HAS_X2, bool HAS_ADD>
+__global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ x2, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           T* __restrict__ dx, const T* __restrict__ dx_add,
+                                                           float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
+                                                           int64_t cols) {
+  constexpr int E = Vec16<T>::N;
+  __shared__ float part[2][R][8][2];  // [buffer][row of the group][wave][s1, s2]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int64_t col = ((int64_t)wid * 64 + lane) * E;  // cols == nw * 64 * E (launcher)
+  float ag[E], ab[E], g[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    ag[e] = ab[e] = 0.f;
+    g[e] = gamma[col + e];
+  }
+  struct Raw {  // the rows stay packed (16 bytes per stream) between the two passes; x^ and dy gamma are recomputed
+    uint4 x[R], d[R], x2[HAS_X2 ? R : 1], add[HAS_ADD ? R : 1];
+    float mu[R], rs[R];
+  };
+  auto request = [&](Raw& w, int64_t row0) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int64_t r = row0 + j < rows ? row0 + j : rows - 1;  // clamp: the tail group recomputes the last row, stores are guarded
+      const int64_t o = r * cols + col;
+      w.mu[j] = mean[r];
+      w.rs[j] = rstd[r];
+      w.x[j] = *reinterpret_cast<const uint4*>(x + o);
+      w.d[j] = *reinterpret_cast<const uint4*>(dy + o);
+      if constexpr (HAS_X2) w.x2[j] = *reinterpret_cast<const uint4*>(x2 + o);
+      if constexpr (HAS_ADD) w.add[j] = *reinterpret_cast<const uint4*>(dx_add + o);
+    }
+  };
+  auto normalised = [&](const Raw& w, int j, float (&xh)[E]) {
+    Vec16<T>::unpack(w.x[j], xh);
+    if constexpr (HAS_X2) {
+      float t[E];
+      Vec16<T>::unpack(w.x2[j], t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) xh[e] += t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) xh[e] = (xh[e] - w.mu[j]) * w.rs[j];
+  };
+  const int64_t stride = (int64_t)gridDim.x * R;
+  Raw cur, nxt;
+  int buf = 0;
+  if ((int64_t)blockIdx.x * R < rows) request(cur, (int64_t)blockIdx.x * R);
+  for (int64_t row0 = (int64_t)blockIdx.x * R; row0 < rows; row0 += stride, buf ^= 1) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float xh[E], d[E];
+      normalised(cur, j, xh);
+      Vec16<T>::unpack(cur.d[j], d);
+      float s1 = 0.f, s2 = 0.f;
+      const bool real = row0 + j < rows;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float gy = d[e] * g[e];
+        s1 += gy;
+        s2 += gy * xh[e];
+        if (real) {
+          ag[e] += d[e] * xh[e];
+          ab[e] += d[e];
+        }
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        part[buf][j][wid][0] = s1;
+        part[buf][j][wid][1] = s2;
+      }
+    }
+    if (row0 + stride < rows) request(nxt, row0 + stride);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float m1 = 0.f, m2 = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        m1 += part[buf][j][w][0];
+        m2 += part[buf][j][w][1];
+      }
+      m1 /= (float)cols;
+      m2 /= (float)cols;
+      if (row0 + j < rows) {
+        float xh[E], d[E], o[E];
+        normalised(cur, j, xh);
+        Vec16<T>::unpack(cur.d[j], d);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = cur.rs[j] * (d[e] * g[e] - m1 - xh[e] * m2);
+        if constexpr (HAS_ADD) {
+          float w[E];
+          Vec16<T>::unpack(cur.add[j], w);
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] += w[e];
+        }
+        Vec16<T>::store(dx + (row0 + j) * cols + col, o);
+      }
+    }
+    cur = nxt;
+  }
+  // contiguous atomics (see ln_bwd_vec_kernel): the lanes' 8-column partials go through LDS first
+  extern __shared__ float cpart[];  // [2][cols]
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    cpart[col + e] = ag[e];
+    cpart[cols + col + e] = ab[e];
+  }
+  __syncthreads();
+  for (int64_t c = threadIdx.x; c < 2 * cols; c += blockDim.x) atomicAdd(c < cols ? d_gamma + c : d_beta + (c - cols), cpart[c]);
+}
+
 template <typename T>
 bool ln_vec_ok(const void* a, const void* b, const void* c, int64_t cols) {
   constexpr int E = Vec16<T>::N;
@@ -291,11 +522,34 @@ void ln_bwd_vec_launch(const void* dy, const void* x, const void* x2, const floa
                        hipStream_t s) {
   constexpr int E = Vec16<T>::N;
   const int nv = (int)((cols + 64 * E - 1) / (64 * E));
-  const int grid = grid_for(rows, 4, 16, 256 * 4);  // >= 16 rows per wave: column partials are reduced per workgroup
-  const size_t lds = 2 * cols * sizeof(float);
-#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
-  switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break;
-                case 5: LNB(5); break; case 6: LNB(6); break; case 7: LNB(7); break; default: LNB(8); break; }
+  if (cols != (int64_t)nv * 64 * E || nv > 8) {  // ragged last chunk: guarded kernel
+    const int grid = grid_for(rows, 4, 16, 256 * 4);
+    const size_t lds = 2 * cols * sizeof(float);
+#define LNG(NVV) hipLaunchKernelGGL((ln_bwd_vec_guarded_kernel<T, NVV>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
+    switch (nv) { case 1: LNG(1); break; case 2: LNG(2); break; case 3: LNG(3); break; case 4: LNG(4); break;
+                  case 5: LNG(5); break; case 6: LNG(6); break; case 7: LNG(7); break; default: LNG(8); break; }
+#undef LNG
+    return;
+  }
+  if (nv >= 3) {  // wide rows: one workgroup of nv waves per row group
+    constexpr int R = 2;
+    const int grid = grid_for(rows, 1, R * 16, 256 * 4);  // >= 16 groups per workgroup (2 cols atomics each at the end)
+#define LNS(X2, ADD) hipLaunchKernelGGL((ln_bwd_split_kernel<T, R, X2, ADD>), dim3(grid), dim3(64 * nv), 2 * cols * sizeof(float), s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
+    if (x2 && dx_add) LNS(true, true);
+    else if (x2) LNS(true, false);
+    else if (dx_add) LNS(false, true);
+    else LNS(false, false);
+#undef LNS
+    return;
+  }
+  // narrow rows: one wave per row, >= 8 rows per wave (2 cols atomics per workgroup at the end), up to 8 workgroups per CU
+  const int grid = grid_for(rows, 4, 8, 256 * 8);
+  const size_t lds = 8 * cols * sizeof(float);
+#define LNB(NVV, X2, ADD) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV, X2, ADD>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
+#define LNB2(NVV) do { if (x2 && dx_add) LNB(NVV, true, true); else if (x2) LNB(NVV, true, false); else if (dx_add) LNB(NVV, false, true); else LNB(NVV, false, false); } while (0)
+  if (nv == 1) LNB2(1);
+  else LNB2(2);
+#undef LNB2
 #undef LNB
 }
 
