@@ -44,6 +44,20 @@ def main():
         split = ops._split_for(N, K, M, 2)
         t = timeit(lambda: ops.gemm(g, x, dw, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC))
         rows.append(("TN  dW   M=%d K=%d N=%d split=%d" % (N, M, K, split), fl / t / 1e12, t * 1e3))
+        if K == 512:  # the epilogues these shapes carry in the model (bias + residual + dropout; GELU derivative + dropout)
+            bias = torch.randn(N, device=dev)
+            res = torch.randn(M, N, device=dev).to(dt)
+            z = torch.randn(M, K, device=dev).to(dt)
+            E = A.EPI_BIAS_COL | A.EPI_RESIDUAL
+            t = timeit(lambda: ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=E, bias_col=bias, aux=res, ld_aux=N, drop=(0.1, 1, 0)))
+            rows.append(("NT  fwd + bias + residual + dropout  K=%d N=%d" % (K, N), fl / t / 1e12, t * 1e3))
+            t = timeit(lambda: ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_GELU, bias_col=bias, aux_out=res, ld_aux=N, drop=(0.1, 1, 0)))
+            rows.append(("NT  fwd + bias + GELU(+z out) + dropout K=%d N=%d" % (K, N), fl / t / 1e12, t * 1e3))
+            t = timeit(lambda: ops.gemm(g, w, dx, M, K, N, N, K, K, b_kmajor=True, epilogue=A.EPI_MUL_DGELU, aux=z, ld_aux=K, drop=(0.1, 1, 0)))
+            rows.append(("NN  dX * gelu'(z) + dropout          N=%d K=%d" % (N, K), fl / t / 1e12, t * 1e3))
+            t = timeit(lambda: ops.gemm(g, w, dx, M, K, N, N, K, K, b_kmajor=True, epilogue=A.EPI_RESIDUAL, aux=z, ld_aux=K))
+            rows.append(("NN  dX + residual                    N=%d K=%d" % (N, K), fl / t / 1e12, t * 1e3))
+            del bias, res, z
         del x, w, g, y, dx, dw
     # attention-shaped batched products: 320 sequences x 8 heads, L = 384
     for d in (320, 64):
