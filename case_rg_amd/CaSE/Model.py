@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import config, ops
-from ..common.Constants import BOS_WORD, UNK_WORD
+from ..common.Constants import BOS_WORD, EOS_WORD, UNK_WORD
 from ..common.Interaction import Interaction
 from ..common.TransformerSeqEncoderDecoder import PointerDecoderCore, TransformerSeqEncoder
 from ..common.Utils import to_sentence
@@ -165,7 +165,7 @@ class ResponseGeneration(nn.Module):
 
 
 class CaSE(nn.Module):
-    def __init__(self, max_span_size, max_target_length, id2vocab, vocab2id, hidden_size, enc_layers=3, dec_layers=4, heads=8):
+    def __init__(self, max_span_size, max_target_length, id2vocab, vocab2id, hidden_size, enc_layers=3, dec_layers=4, heads=8, early_stop=False):
         super().__init__()
         V = len(vocab2id)
         self.UNK = vocab2id[UNK_WORD]
@@ -182,6 +182,8 @@ class CaSE(nn.Module):
         self.id2vocab = id2vocab
         self.vocab_size = len(id2vocab)
         self.vocab2id = vocab2id
+        if early_stop:  # greedy decoding ends once every answer of the batch has produced EOS (off = the reference's fixed T steps)
+            self.response_generation.decoder.eos_id = vocab2id[EOS_WORD]
 
     def to_sentence(self, data, batch_indices):
         return to_sentence(batch_indices, self.id2vocab)

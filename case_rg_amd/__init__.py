@@ -31,7 +31,8 @@ def namespace():
         TransformerSeqDecoder=TransformerSeqEncoderDecoder.TransformerSeqDecoder, CaSE=CaSE, Masque=Masque,
         generate_square_subsequent_mask=Utils.generate_square_subsequent_mask, build_map=Utils.build_map,
         universal_sentence_embedding=Utils.universal_sentence_embedding, topk=Utils.topk,
-        CumulativeTrainer=CumulativeTrainer.CumulativeTrainer, lr_schedule=schedule.get_cosine_with_hard_restarts_schedule_with_warmup)
+        CumulativeTrainer=CumulativeTrainer.CumulativeTrainer, lr_schedule=schedule.get_cosine_with_hard_restarts_schedule_with_warmup,
+        to_sentence=Utils.to_sentence, remove_duplicate=Utils.remove_duplicate)
 
 
 # Hot-path modules that replace the reference's own (north_star / SURVEY 8a); everything else of the caller's ``common`` /

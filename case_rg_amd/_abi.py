@@ -75,6 +75,7 @@ SIGNATURES = {
     "case_nll_gather_fwd": [ptr, ptr, ptr, i64, i64, ptr],
     "case_nll_gather_bwd": [ptr, ptr, ptr, ptr, i64, i64, ptr],
     "case_row_argmax": [ptr, ptr, ptr, i64, i64, i64, ptr],
+    "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
 }
 
 

@@ -65,6 +65,12 @@ class PointerDecoderCore(nn.Module):
         layer = TransformerDecoderLayer(H, nhead=nhead, dim_feedforward=H, dropout=0.1, activation='gelu')
         self.decs = nn.ModuleList([TransformerDecoder(layer, num_layers=num_layers, norm=None) for _ in range(num_memories)])
         self.attns = nn.ModuleList([BilinearAttention(query_width, H, H) for _ in range(num_memories)])
+        # EOS-aware early stop of greedy decoding.  None = the reference's behaviour: always max_target_length steps
+        # (CaSE/Model.py:94).  With an id, a finished answer is continued with PAD and the loop ends once EVERY answer of the
+        # batch has produced EOS -- checked every ``eos_check_every`` steps, so one host sync per 8 tokens, none per token.
+        self.eos_id = None
+        self.eos_check_every = 8
+        self.last_greedy_steps = 0
 
     # ------------------------------------------------------------------------------------------
     def _prepare(self, encode_memories, encode_masks, encode_weights, batch_size):
@@ -114,6 +120,8 @@ class PointerDecoderCore(nn.Module):
         ids = self._bos(B, BOS, dev)
         feat = None if feature_of is None else feature_of(1)
         picked = []
+        finished = None if self.eos_id is None else torch.zeros(B, dtype=torch.bool, device=dev)
+        capturing = torch.cuda.is_current_stream_capturing()  # a captured pass cannot branch on device data: fixed T steps
         for t in range(max_target_length):
             tok_valid = ids.ne(0)
             hist_valid[:, t] = tok_valid[:, 0]
@@ -131,8 +139,18 @@ class PointerDecoderCore(nn.Module):
                 copies.append(p)
             dec_out, gen, dist = self._head(dec_in, x, ctxs, copies, feat, source_map)
             ids = ops.row_argmax(dist[:, -1])[0].unsqueeze(1)
+            if finished is not None:
+                ids = ids.masked_fill(finished.unsqueeze(1), 0)  # PAD behind a finished answer (to_sentence stops at EOS anyway)
+                finished = finished | ids[:, 0].eq(self.eos_id)
             picked.append(ids)
-        return dec_out, gen, dist, torch.cat(picked, dim=-1)
+            if (finished is not None and not capturing and (t + 1) % self.eos_check_every == 0 and t + 1 < max_target_length
+                    and bool(finished.all())):
+                break
+        self.last_greedy_steps = len(picked)
+        answer = torch.cat(picked, dim=-1)
+        if answer.size(1) < max_target_length:
+            answer = torch.nn.functional.pad(answer, (0, max_target_length - answer.size(1)))
+        return dec_out, gen, dist, answer
 
     def _generate(self, gen_in, hidden_drop):
         """gen = softmax(W_v (drop(W_h x + b)))  -- f32 logits and probabilities (K10)."""

@@ -81,9 +81,28 @@ def topk(gen_output, k=1, PAD=None, BOS=None, UNK=None):
     return val.unsqueeze(1), idx.unsqueeze(1)
 
 
+_special_ids = {}
+
+
+def _specials(id2vocab):
+    """ids of BOS / PAD / EOS in ``id2vocab`` (-1 when absent), cached per vocabulary object."""
+    key = id(id2vocab)
+    if key not in _special_ids:
+        items = id2vocab.items() if hasattr(id2vocab, "items") else enumerate(id2vocab)
+        inv = {w: i for i, w in items if w in (BOS_WORD, PAD_WORD, EOS_WORD)}
+        _special_ids[key] = tuple(inv.get(w, -1) for w in (BOS_WORD, PAD_WORD, EOS_WORD))
+    return _special_ids[key]
+
+
 def to_sentence(batch_indices, id2vocab):
-    """ids -> token lists: drop BOS/PAD, stop at EOS, empty -> [UNK] (reference :200-217).  One device->host
-    copy for the whole batch instead of one ``.item()`` per token."""
+    """ids -> token lists: drop BOS / PAD, stop at EOS, empty -> [UNK] (reference :200-217).  Ids on the GPU are filtered and
+    front-packed by one kernel (K13 post-processing) and come back with ONE device->host copy for the whole batch, instead of
+    the reference's ``.item()`` per generated token; host ids take the plain loop."""
+    if torch.is_tensor(batch_indices) and batch_indices.is_cuda and batch_indices.dim() == 2:
+        bos, pad, eos = _specials(id2vocab)
+        kept, count = ops.sentence_compact(batch_indices.long(), bos, pad, eos)
+        rows, lens = kept.tolist(), count.tolist()
+        return [[id2vocab[i] for i in row[:n]] if n else [UNK_WORD] for row, n in zip(rows, lens)]
     rows = batch_indices.tolist() if torch.is_tensor(batch_indices) else batch_indices
     out = []
     for row in rows:

@@ -415,6 +415,33 @@ extern "C" int case_nll_gather_bwd(const float* dist, const int64_t* target, con
   return case_check_launch("case_nll_gather_bwd");
 }
 
+namespace {
+// ---- greedy post-processing (common/Utils.py:200-217 to_sentence): per answer row drop BOS / PAD, stop at the first EOS ----
+// one thread per row (T <= a few hundred); out [B, T] receives the kept ids front-packed (pad behind), len [B] their count
+__global__ void sentence_compact_kernel(const int64_t* __restrict__ ids, int64_t* __restrict__ out, int32_t* __restrict__ len,
+                                        int64_t B, int64_t T, int64_t bos, int64_t pad, int64_t eos) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  bool open = true;
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t id = ids[b * T + t];
+    if (open && id == eos) open = false;
+    if (open && id != bos && id != pad) out[b * T + n++] = id;
+  }
+  len[b] = n;
+  for (int64_t t = n; t < T; ++t) out[b * T + t] = pad;
+}
+}  // namespace
+
+extern "C" int case_sentence_compact(const int64_t* ids, int64_t* out, int32_t* len, int64_t B, int64_t T, int64_t bos, int64_t pad,
+                                     int64_t eos, case_stream_t stream) {
+  CASE_REQUIRE(ids && out && len && B > 0 && T > 0, "case_sentence_compact: bad argument");
+  hipLaunchKernelGGL(sentence_compact_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, ids, out, len, B, T, bos,
+                     pad, eos);
+  return case_check_launch("case_sentence_compact");
+}
+
 extern "C" int case_row_argmax(const float* x, int64_t* idx, float* val, int64_t rows, int64_t cols, int64_t ld,
                                case_stream_t stream) {
   CASE_REQUIRE(x && idx && rows > 0 && cols > 0 && ld >= cols, "case_row_argmax: bad argument");

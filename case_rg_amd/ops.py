@@ -1114,3 +1114,13 @@ def row_argmax(x):
     val = torch.empty(rows, dtype=torch.float32, device=x.device)
     A.call("case_row_argmax", _ptr(x), _ptr(idx), _ptr(val), rows, cols, cols, _stream())
     return idx, val
+
+
+def sentence_compact(ids, bos, pad, eos):
+    """ids int64 [B, T] on the GPU -> (kept ids front-packed [B, T], count int32 [B]): BOS / PAD dropped, cut at the first EOS."""
+    ids = ids.contiguous()
+    B, T = ids.shape
+    out = torch.empty_like(ids)
+    n = torch.empty(B, dtype=torch.int32, device=ids.device)
+    A.call("case_sentence_compact", _ptr(ids), _ptr(out), _ptr(n), B, T, bos, pad, eos, _stream())
+    return out, n

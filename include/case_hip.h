@@ -282,6 +282,12 @@ int case_nll_gather_bwd(const float* dist, const int64_t* target, const float* g
 int case_row_argmax(const float* x, int64_t* idx, float* val, int64_t rows, int64_t cols, int64_t ld,
                     case_stream_t stream);
 
+/* Greedy post-processing on the device (common/Utils.py:200-217 to_sentence): per row of ids [B, T] drop the BOS / PAD ids and
+ * everything from the first EOS on; out [B, T] holds the kept ids front-packed (pad behind), len [B] their count.  One host
+ * copy of (out, len) replaces the reference's `.item()` per generated token.  Pass -1 for a special id the vocabulary lacks. */
+int case_sentence_compact(const int64_t* ids, int64_t* out, int32_t* len, int64_t B, int64_t T, int64_t bos, int64_t pad,
+                          int64_t eos, case_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

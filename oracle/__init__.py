@@ -15,7 +15,7 @@ from .blocks import (  # noqa: F401
     TransformerEncoder, TransformerDecoderLayer, GenericTransformerDecoderLayer,
     TransformerDecoder, TransformerBlock, BilinearAttention, Interaction, Highway,
     causal_additive_mask, masked_mean, one_hot_map, generate_square_subsequent_mask, build_map,
-    universal_sentence_embedding, topk,
+    universal_sentence_embedding, topk, to_sentence, remove_duplicate,
 )
 from .models import (  # noqa: F401
     TransformerSeqEncoder, TransformerSeqDecoder, CaSETransformerSeqDecoder,

@@ -384,3 +384,39 @@ def topk(gen_output, k=1):
     """k == 1 only: (max value, lowest argmax index), keepdim.  common/Utils.py:156-168."""
     assert k == 1
     return torch.max(gen_output, dim=1, keepdim=True)
+
+
+# ---- answer post-processing (reference: common/Utils.py:180-217) ----------------------------------------------------------
+def to_sentence(batch_indices, id2vocab):
+    """common/Utils.py:200-217: per row skip [unused0] (BOS) and [PAD], stop at [unused1] (EOS), empty -> [[UNK]]."""
+    out = []
+    for row in batch_indices:
+        words = []
+        for index in row:
+            w = id2vocab[int(index)]
+            if w in ("[unused0]", "[PAD]"):
+                continue
+            if w == "[unused1]":
+                break
+            words.append(w)
+        out.append(words if words else ["[UNK]"])
+    return out
+
+
+def remove_duplicate(sents, n=3):
+    """common/Utils.py:180-198: repeatedly cut the shortest tail (>= n tokens) whose tokens all occur earlier in the sentence."""
+    def once():
+        changed = False
+        for b in range(len(sents)):
+            sent = sents[b]
+            if len(sent) <= n:
+                continue
+            for i in range(len(sent) - n):
+                index = len(sent) - i - n
+                if all(elem in sent[:index] for elem in sent[index:]):
+                    sents[b] = sent[:index]
+                    changed = True
+                    break
+        return changed
+    while once():
+        pass

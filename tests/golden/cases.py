@@ -362,6 +362,38 @@ def case_masque_test(ns, dev):
 
 
 # ---------------------------------------------------------------------------------------------
+# answer post-processing: to_sentence + remove_duplicate (common/Utils.py:180-217) on crafted id rows
+# ---------------------------------------------------------------------------------------------
+def case_sentences(ns, dev):
+    v2i, i2v = make_vocab(V)
+    bos, eos, pad, unk = v2i["[unused0]"], v2i["[unused1]"], v2i["[PAD]"], v2i["[UNK]"]
+    rng = np.random.RandomState(301)
+    rows = rng.randint(104, 120, size=(12, 14))
+    rows[0, 5] = eos                      # plain stop
+    rows[1, 0] = bos; rows[1, 3] = pad; rows[1, 9] = eos   # BOS / PAD skipped before the stop
+    rows[2, 0] = eos                      # empty -> [UNK]
+    rows[3, :] = pad                      # only padding -> [UNK]
+    rows[4, 2] = eos; rows[4, 6] = eos    # second EOS irrelevant
+    rows[5, 4:] = np.tile(rows[5, 1:4], 4)[:10]            # repeated tail: remove_duplicate cuts it
+    rows[6, 7:10] = rows[6, 2:5]; rows[6, 10] = eos        # repeated trigram then EOS
+    rows[7, 13] = eos
+    rows[8, 1] = bos; rows[8, 2] = bos                     # BOS in the middle is skipped, no stop
+    rows[9, 3:] = rows[9, 2]                                # one token repeated to the end
+    ids = torch.from_numpy(rows).to(dev)
+    sents = ns.to_sentence(ids, i2v)
+    before = [list(x) for x in sents]
+    ns.remove_duplicate(sents)
+
+    def encode(lists):
+        out = np.full((len(lists), rows.shape[1] + 1), -1, dtype=np.int64)
+        for b, words in enumerate(lists):
+            out[b, :len(words)] = [v2i[w] for w in words]
+        return torch.from_numpy(out)
+
+    return {"in_ids": ids, "sentences": encode(before), "deduplicated": encode(sents), "unk": torch.tensor([unk])}
+
+
+# ---------------------------------------------------------------------------------------------
 # trainer loop (SURVEY a15 / cfg 1 plumbing): CumulativeTrainer.train_epoch with gradient accumulation, an odd number of
 # batches (end-of-epoch flush of a partial group: optimizer step WITHOUT clip / EMA, reference :122-126), clip-norm 1,
 # Adam, LR schedule, EMA; then predict().  The reference's loop, the oracle model under this package's loop and the HIP

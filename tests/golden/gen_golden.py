@@ -59,7 +59,8 @@ def reference_namespace():
         CaSE=case_model.CaSE, Masque=masque_model.Masque,
         generate_square_subsequent_mask=utils.generate_square_subsequent_mask, build_map=utils.build_map,
         universal_sentence_embedding=utils.universal_sentence_embedding, topk=utils.topk,
-        CumulativeTrainer=trainer.CumulativeTrainer, lr_schedule=_lr_schedule())
+        CumulativeTrainer=trainer.CumulativeTrainer, lr_schedule=_lr_schedule(), to_sentence=utils.to_sentence,
+        remove_duplicate=utils.remove_duplicate)
     return ns
 
 

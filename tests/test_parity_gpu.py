@@ -219,3 +219,60 @@ def test_gradsync_over_rccl_on_one_rank(ns):
             assert err <= 1e-4 * scale, "%s: %.3e vs scale %.3e" % (n, err, scale)
     finally:
         dist.destroy_process_group()
+
+
+def test_sentences_on_device_match_reference_fixture(ns):
+    """to_sentence through the device compaction kernel (ids on the GPU) + remove_duplicate vs the reference's own output."""
+    rec = cases.CASES["sentences"](ns, torch.device("cuda"))
+    golden = load_golden("sentences")
+    for k in ("sentences", "deduplicated"):
+        assert np.array_equal(to_np(rec[k]), golden[k]), k
+
+
+def test_greedy_early_stop_and_graph_replay(ns):
+    """(1) EOS-aware early stop: same sentences as the reference's fixed-T loop, fewer steps, PAD behind finished answers;
+    (2) one whole greedy pass captured in a hipGraph replays to identical ids (cfg 4's captured-step requirement)."""
+    from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+    V_, T = 200, 24
+    v2i, i2v = make_vocab(V_)
+    model = fill_params(ns.CaSE(4, T, i2v, v2i, 32), 153, gain=3.0).cuda().eval()
+    b = {k: v.cuda() for k, v in synth_batch(4, 3, 12, 8, 6, V_, seed=152, model="case").items()}
+    dec = model.response_generation.decoder
+    with torch.no_grad():
+        full = model(dict(b), method="test")["answer"]
+        assert dec.last_greedy_steps == T
+        # graph capture of the same pass (fixed T steps inside a capture): replay must reproduce the eager ids
+        static_out = {}
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(dict(b), method="test")  # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out["answer"] = model(dict(b), method="test")["answer"]
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out["answer"], full), "hipGraph replay of the greedy pass differs from the eager pass"
+        # declare the most frequent generated token to be EOS and keep the batch rows that emit it (items are independent),
+        # so that every remaining answer finishes before T
+        eos = int(torch.mode(full.reshape(-1)).values)
+        rows = [r for r in range(full.size(0)) if (full[r] == eos).any()]
+        assert rows, "no row emits the chosen token"
+        sub = {k: v[rows] for k, v in b.items()}
+        full = model(dict(sub), method="test")["answer"]
+        ends = [int((row == eos).nonzero()[0]) for row in full]
+        dec.eos_id, dec.eos_check_every = eos, 4
+        try:
+            early = model(dict(sub), method="test")["answer"]
+        finally:
+            dec.eos_id = None
+        assert dec.last_greedy_steps <= min(T, ((max(ends) + 1 + 3) // 4) * 4), "the loop did not stop after the last EOS"
+        if max(ends) + 1 <= T - 4:
+            assert dec.last_greedy_steps < T
+        for r, cut in enumerate(ends):
+            assert torch.equal(early[r, :cut + 1], full[r, :cut + 1]) and (early[r, cut + 1:] == 0).all()
+        i2v_eos = dict(i2v)
+        i2v_eos[v2i["[unused1]"]], i2v_eos[eos] = "tok_old_eos", "[unused1]"
+        assert ns.to_sentence(early, i2v_eos) == ns.to_sentence(full, i2v_eos)
