@@ -18,6 +18,7 @@ def namespace():
     """Reference-named classes and helpers in one namespace (what the shared parity cases consume)."""
     from .CaSE.Model import CaSE
     from .Masque.Model import Masque
+    from .evaluation import rouge as _rouge
     from .common import (BilinearAttention, CumulativeTrainer, Highway, Interaction, PositionalEmbedding, TransformerBlock,
                          TransformerDecoder, TransformerEncoder, TransformerSeqEncoderDecoder, Utils, schedule)
     return _types.SimpleNamespace(
@@ -32,7 +33,8 @@ def namespace():
         generate_square_subsequent_mask=Utils.generate_square_subsequent_mask, build_map=Utils.build_map,
         universal_sentence_embedding=Utils.universal_sentence_embedding, topk=Utils.topk,
         CumulativeTrainer=CumulativeTrainer.CumulativeTrainer, lr_schedule=schedule.get_cosine_with_hard_restarts_schedule_with_warmup,
-        to_sentence=Utils.to_sentence, remove_duplicate=Utils.remove_duplicate)
+        to_sentence=Utils.to_sentence, remove_duplicate=Utils.remove_duplicate, rouge_l=_rouge.rouge_l,
+        eval_rouge_l=_rouge.eval_rouge_l)
 
 
 # Hot-path modules that replace the reference's own (north_star / SURVEY 8a); everything else of the caller's ``common`` /

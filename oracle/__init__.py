@@ -21,3 +21,4 @@ from .models import (  # noqa: F401
     TransformerSeqEncoder, TransformerSeqDecoder, CaSETransformerSeqDecoder,
     MasqueTransformerSeqDecoder, CaSE, Masque, SPECIALS,
 )
+from .rouge import rouge_l, eval_rouge_l  # noqa: F401,E402

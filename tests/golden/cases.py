@@ -394,6 +394,26 @@ def case_sentences(ns, dev):
 
 
 # ---------------------------------------------------------------------------------------------
+# ROUGE-L: sentence-level F / P / R with the reference's F-measure, and the evaluation script's aggregate
+# (best over ground truths, x100, mean, 2 decimals) on synthetic token strings
+# ---------------------------------------------------------------------------------------------
+def case_rouge_l(ns, dev):
+    rng = np.random.RandomState(311)
+    words = ["w%d" % i for i in range(12)]
+
+    def sentence(n):
+        return " ".join(words[i] for i in rng.randint(0, len(words), size=n))
+
+    hyps = [sentence(rng.randint(1, 25)) for _ in range(24)]
+    refs = [[sentence(rng.randint(1, 25)) for _ in range(rng.randint(1, 4))] for _ in range(24)]
+    refs[3] = [hyps[3]]                       # exact match
+    refs[4] = ["zz " + hyps[4] + " yy"]       # hypothesis contained in the ground truth
+    hyps[5], refs[5] = "w0", ["w1 w2"]        # nothing in common
+    fpr = torch.tensor([[ns.rouge_l(h, t) for t in (r + r + r)[:3]] for h, r in zip(hyps, refs)], dtype=torch.float64)
+    return {"fpr": fpr, "rouge_l_f1": torch.tensor([ns.eval_rouge_l(hyps, refs)], dtype=torch.float64)}
+
+
+# ---------------------------------------------------------------------------------------------
 # trainer loop (SURVEY a15 / cfg 1 plumbing): CumulativeTrainer.train_epoch with gradient accumulation, an odd number of
 # batches (end-of-epoch flush of a partial group: optimizer step WITHOUT clip / EMA, reference :122-126), clip-norm 1,
 # Adam, LR schedule, EMA; then predict().  The reference's loop, the oracle model under this package's loop and the HIP

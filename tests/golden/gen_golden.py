@@ -49,6 +49,8 @@ def reference_namespace():
     import common.TransformerSeqEncoderDecoder as sed
     import common.CumulativeTrainer as trainer
     import common.Utils as utils
+    import evaluation.Eval_Rouge as eval_rouge
+    import evaluation.Rouge as rouge
 
     ns = types.SimpleNamespace(
         PositionalEmbedding=pe.PositionalEmbedding, TransformerEncoderLayer=te.TransformerEncoderLayer,
@@ -60,7 +62,9 @@ def reference_namespace():
         generate_square_subsequent_mask=utils.generate_square_subsequent_mask, build_map=utils.build_map,
         universal_sentence_embedding=utils.universal_sentence_embedding, topk=utils.topk,
         CumulativeTrainer=trainer.CumulativeTrainer, lr_schedule=_lr_schedule(), to_sentence=utils.to_sentence,
-        remove_duplicate=utils.remove_duplicate)
+        remove_duplicate=utils.remove_duplicate,
+        rouge_l=lambda hyp, ref: rouge.rouge_l_sentence_level([hyp], [ref]),
+        eval_rouge_l=lambda run, ref: eval_rouge.eval_rouge(run, ref)["ROUGE_L_F1"])
     return ns
 
 
