@@ -110,7 +110,9 @@ def build(a, device):
         model = Masque(a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
     init_params(model)
     trainer = CumulativeTrainer(model, None, None, device.index, a.gpus)
-    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, fused=True)  # CaSE/Run.py:27 (same update rule, one multi-tensor kernel)
+    from case_rg_amd.optim import FusedAdam
+    # CaSE/Run.py:27 optim.Adam(lr=2.5e-4): same update rule; the trainer's clip / EMA and the bf16 operand refresh ride in its pass (K15)
+    opt = FusedAdam(model.parameters(), lr=2.5e-4, low_precision=torch.bfloat16 if a.dtype == "bf16" else None)
     sched = get_cosine_with_hard_restarts_schedule_with_warmup(opt, 2000, 100000)
     rank = dist.get_rank() if dist.is_initialized() else 0
     batch = synth_batch(a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=123456 + rank,

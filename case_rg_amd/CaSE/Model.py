@@ -57,6 +57,7 @@ class CaSETransformerSeqDecoder(PointerDecoderCore):
     def forward(self, encode_memories, BOS, UNK, source_map, groundtruth_index=None, additional_decoder_feature=None,
                 encode_weights=None, encode_masks=None, init_decoder_state=None, max_target_length=None):
         B = source_map.size(0)
+        source_map = self._sorted(source_map)
         mems, valid, weights = self._prepare(encode_memories, encode_masks, encode_weights, B)
         if max_target_length is None:
             max_target_length = groundtruth_index.size(1)

@@ -44,6 +44,7 @@ class MasqueTransformerSeqDecoder(PointerDecoderCore):
     def forward(self, encode_memories, BOS, UNK, source_map, encode_masks=None, encode_weights=None,
                 groundtruth_index=None, init_decoder_state=None, max_target_length=None):
         B = source_map.size(0)
+        source_map = self._sorted(source_map)
         mems, valid, weights = self._prepare(encode_memories, encode_masks, encode_weights, B)
         if max_target_length is None:
             max_target_length = groundtruth_index.size(1)

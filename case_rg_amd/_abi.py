@@ -15,7 +15,7 @@ F32, BF16 = 0, 1
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
-i32, i64, u64, f32, ptr = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+i32, i64, u64, f32, f64, ptr = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_void_p
 
 
 class GemmDesc(C.Structure):
@@ -72,10 +72,14 @@ SIGNATURES = {
     "case_additive_scores_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i64, i64, i32, ptr],
     "case_copy_scatter_fwd": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
     "case_copy_scatter_bwd": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
+    "case_source_sort": [ptr, ptr, i64, i64, i64, ptr],
+    "case_copy_scatter_sorted_fwd": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
     "case_nll_gather_fwd": [ptr, ptr, ptr, i64, i64, ptr],
     "case_nll_gather_bwd": [ptr, ptr, ptr, ptr, i64, i64, ptr],
     "case_row_argmax": [ptr, ptr, ptr, i64, i64, i64, ptr],
     "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
+    "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr],
+    "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, f64, f64, f64, ptr],
 }
 
 
@@ -89,6 +93,8 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.case_optim_chunk_elems.restype = C.c_int
+    lib.case_optim_chunk_elems.argtypes = []
     lib.case_version.restype = C.c_int
     lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()
     lib.case_gemm_tile_for.argtypes = [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr]

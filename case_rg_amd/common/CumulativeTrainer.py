@@ -6,7 +6,11 @@ prediction lists.  What differs (none of it changes the numbers):
   * data parallelism is ``case_rg_amd.parallel.GradSync`` (bucketed RCCL all-reduce overlapped with backward) instead of
     a DistributedDataParallel wrapper, so ``self.model`` stays the bare module and ``serialize`` also works on one GPU / CPU
     (the reference crashes on ``self.model.module`` there);
-  * the per-loss ``.cpu().item()`` (3 device->host syncs per step, :57) is one stacked copy.
+  * the per-loss ``.cpu().item()`` (3 device->host syncs per step, :57) is one stacked copy;
+  * batches are uploaded one ahead on a side stream from pinned memory (``utils.pipeline.DevicePrefetcher``)
+    instead of blocking ``.cuda()`` calls inside the step;
+  * ``save_checkpoint`` / ``load_checkpoint`` write what a resume needs next to the reference's weights-only
+    ``<epoch>.pkl`` (:80-86): optimizer moments + step, scheduler, EMA shadow, the accumulation counter and the RNG streams.
 """
 import os
 import sys
@@ -16,8 +20,10 @@ import torch
 import torch.distributed as dist
 from torch.utils.data.distributed import DistributedSampler
 
-from .. import ops
+from .. import config, ops
+from ..optim import FusedAdam
 from ..parallel import GradSync
+from ..utils.pipeline import DevicePrefetcher
 from .EMA import EMA
 
 
@@ -31,12 +37,6 @@ def init_params(model, escape=None):
     if hasattr(model, 'reset_parameters'):
         model.reset_parameters()
     ops.invalidate_param_cache()  # writes through .data leave _version alone
-
-
-def _to_device(data):
-    if not torch.cuda.is_available():
-        return data
-    return {k: (v.cuda(non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
 
 
 class CumulativeTrainer(object):
@@ -69,10 +69,13 @@ class CumulativeTrainer(object):
         if boundary:
             if self.sync is not None:
                 self.sync.finish()
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1)
-            optimizer.step()
-            ops.invalidate_param_cache()  # optimizers that write through p.data leave _version alone
-            self.ema.update()
+            if isinstance(optimizer, FusedAdam):  # clip + Adam + EMA + bf16 operand refresh in one multi-tensor pass (K15)
+                optimizer.step(clip_norm=1.0, ema=self.ema)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1)
+                optimizer.step()
+                ops.invalidate_param_cache()  # optimizers that write through p.data leave _version alone
+                self.ema.update()
             if scheduler is not None:
                 scheduler.step()
             optimizer.zero_grad()
@@ -84,6 +87,48 @@ class CumulativeTrainer(object):
         output_path = os.path.join(output_path, 'model/')
         os.makedirs(output_path, exist_ok=True)
         torch.save(self.model.state_dict(), os.path.join(output_path, '.'.join([str(epoch), 'pkl'])))
+
+    def save_checkpoint(self, epoch, output_path, optimizer, scheduler=None):
+        """Resumable state of the loop after ``epoch``: ``<output_path>/model/<epoch>.ckpt`` (rank 0 only, like serialize)."""
+        if self.local_rank not in (0, None):
+            return None
+        output_path = os.path.join(output_path, 'model/')
+        os.makedirs(output_path, exist_ok=True)
+        state = {
+            'epoch': epoch,
+            'model': self.model.state_dict(),
+            'optimizer': optimizer.state_dict(),
+            'scheduler': None if scheduler is None else scheduler.state_dict(),
+            'ema_shadow': dict(self.ema.shadow),
+            'ema_decay': self.ema.decay,
+            'accumulation_count': self.accumulation_count,
+            'rng': {'torch': torch.get_rng_state(), 'dropout_counter': config.rng_state(),
+                    'cuda': torch.cuda.get_rng_state() if torch.cuda.is_available() else None},
+        }
+        path = os.path.join(output_path, '.'.join([str(epoch), 'ckpt']))
+        torch.save(state, path)
+        return path
+
+    def load_checkpoint(self, path, optimizer, scheduler=None):
+        """Restore everything ``save_checkpoint`` wrote (every rank loads the same file); returns the epoch it was taken after."""
+        device = next(self.model.parameters()).device
+        state = torch.load(path, map_location=device, weights_only=False)
+        self.model.load_state_dict(state['model'], strict=True)
+        optimizer.load_state_dict(state['optimizer'])
+        if scheduler is not None and state['scheduler'] is not None:
+            scheduler.load_state_dict(state['scheduler'])
+        named = dict(self.model.named_parameters())
+        if set(state['ema_shadow']) != set(self.ema.shadow):
+            raise RuntimeError('checkpoint EMA shadow does not match the model\'s trainable parameters')
+        self.ema.shadow = {n: t.to(named[n].device, copy=True) for n, t in state['ema_shadow'].items()}
+        self.ema.decay = state['ema_decay']
+        self.accumulation_count = state['accumulation_count']
+        torch.set_rng_state(state['rng']['torch'].cpu())
+        if state['rng']['cuda'] is not None and torch.cuda.is_available():
+            torch.cuda.set_rng_state(state['rng']['cuda'].cpu())
+        config.set_rng_state(state['rng']['dropout_counter'])
+        ops.invalidate_param_cache()  # load_state_dict copies in place under no_grad: cached bf16 operand copies are stale
+        return state['epoch']
 
     def _loader(self, dataset, collate_fn, batch_size, shuffle, epoch=None):
         if dist.is_available() and dist.is_initialized():
@@ -106,9 +151,9 @@ class CumulativeTrainer(object):
             print(*msg)
             sys.stdout.flush()
 
-        for j, data in enumerate(loader, 0):
+        for j, data in enumerate(DevicePrefetcher(loader), 0):  # batch j+1 is uploaded on a side stream while j computes (f3)
             count += 1
-            bloss = self.train_batch(epoch, _to_device(data), method=method, optimizer=optimizer, scheduler=scheduler)
+            bloss = self.train_batch(epoch, data, method=method, optimizer=optimizer, scheduler=scheduler)
             if j > 0 and j % 100 == 0:
                 report()
         if self.accumulation_count % self.accumulation_steps != 0:  # flush a partial group (no clip / EMA, reference :122-126)
@@ -126,7 +171,6 @@ class CumulativeTrainer(object):
         self.model.eval()
         rs = []
         with torch.no_grad():
-            for data in self._loader(dataset, collate_fn, batch_size, False):
-                data = _to_device(data)
+            for data in DevicePrefetcher(self._loader(dataset, collate_fn, batch_size, False)):
                 rs.append([data, self.model(data, method=method)])
         return rs

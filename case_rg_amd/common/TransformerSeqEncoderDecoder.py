@@ -80,6 +80,13 @@ class PointerDecoderCore(nn.Module):
         weights = None if encode_weights is None else [w.reshape(batch_size, -1) for w in encode_weights]
         return mems, valid, weights
 
+    def _sorted(self, source_map):
+        """The batch's source map with its (token, position) keys sorted on the device, once per forward: every
+        pointer scatter of the batch -- one per training step, one per generated token -- then adds run by run without atomics."""
+        if torch.is_tensor(source_map) and source_map.is_cuda and ops.SortedSource.fits(source_map, self.tgt_vocab_size):
+            return ops.SortedSource(source_map, self.tgt_vocab_size)
+        return source_map
+
     def _memory_cache(self, mems):
         """Step-invariant projections of the memories (cross-attention K/V per layer, additive-attention keys)."""
         return [dict(kvs=self.decs[i].project_memory(m), uh=self.attns[i].project_keys(m)) for i, m in enumerate(mems)]
@@ -168,7 +175,7 @@ class PointerDecoderCore(nn.Module):
 
     @staticmethod
     def _scatter(ptr, source_map, V):
-        if source_map.dtype == torch.int64 and source_map.dim() == 2:
+        if isinstance(source_map, ops.SortedSource) or (source_map.dtype == torch.int64 and source_map.dim() == 2):
             return ops.copy_scatter(source_map, ptr, V)
         # dense [B, S, V] one-hot given by an API-compatible caller: recover the ids once, then scatter
         return ops.copy_scatter(source_map.argmax(dim=-1), ptr * source_map.sum(dim=-1).unsqueeze(1), V)
@@ -208,6 +215,7 @@ class TransformerSeqDecoder(PointerDecoderCore):
                 groundtruth_index=None, init_decoder_state=None, max_target_length=None):
         source_map = self._source(source_maps) if isinstance(source_maps, (list, tuple)) else source_maps
         B = source_map.size(0)
+        source_map = self._sorted(source_map)
         mems, valid, weights = self._prepare(encode_memories, encode_masks, encode_weights, B)
         if max_target_length is None:
             max_target_length = groundtruth_index.size(1)

@@ -39,6 +39,15 @@ def manual_seed(seed):
     _state["offset"] = 0
 
 
+def rng_state():
+    """(seed, offset) of the dropout counter stream -- what a resumable checkpoint stores."""
+    return _state["seed"], _state["offset"]
+
+
+def set_rng_state(state):
+    _state["seed"], _state["offset"] = int(state[0]), int(state[1])
+
+
 def next_rng(numel):
     """Reserve ``numel`` counters; returns (seed, offset) for one dropout site."""
     off = _state["offset"]

@@ -273,6 +273,73 @@ __global__ void copy_scatter_bwd_kernel(const int64_t* __restrict__ src, const f
   }
 }
 
+// ---- K11, sorted form (the source map sorted on the device once per batch) -----------
+// keys[b, i] = (token << 15 | position), ascending; out-of-vocabulary ids become 0xFFFFFFFF and sort behind every valid key.
+// One workgroup per batch row, bitonic network over the next power of two in LDS (S <= 32768: 128 KiB).
+__global__ __launch_bounds__(1024) void source_sort_kernel(const int64_t* __restrict__ src, uint32_t* __restrict__ keys, int64_t S,
+                                                            int64_t V, int n) {
+  extern __shared__ uint32_t sk[];
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    uint32_t k = 0xFFFFFFFFu;
+    if (i < S) {
+      const int64_t tok = src[b * S + i];
+      if (tok >= 0 && tok < V) k = ((uint32_t)tok << 15) | (uint32_t)i;
+    }
+    sk[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint32_t x = sk[i], y = sk[p];
+          if ((x > y) == ((i & k) == 0)) {
+            sk[i] = y;
+            sk[p] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < S; i += 1024) keys[b * S + i] = sk[i];
+}
+
+// dist[b, t, token] += sum of w[b, t, position] over each run of equal tokens in the sorted keys: one workgroup per (b, t) row
+// walks the keys in chunks of 256; the last lane of a run sums it (fixed order) and adds it to the row with a plain
+// read-modify-write -- a token's run in a later chunk is added by a later iteration of the same workgroup, so there are no
+// atomics and the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void copy_scatter_sorted_kernel(const uint32_t* __restrict__ keys, const float* __restrict__ w,
+                                                                  float* __restrict__ dist, int64_t Tn, int64_t S, int64_t V) {
+  __shared__ uint32_t tk[257];
+  __shared__ float tv[256];
+  const int64_t bt = blockIdx.x, b = bt / Tn;
+  const uint32_t* k = keys + b * S;
+  const float* wr = w + bt * S;
+  float* d = dist + bt * V;
+  for (int64_t base = 0; base < S; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t key = i < S ? k[i] : 0xFFFFFFFFu;
+    const bool valid = key != 0xFFFFFFFFu;
+    tk[threadIdx.x] = valid ? (key >> 15) : 0xFFFFFFFFu;
+    tv[threadIdx.x] = valid ? wr[key & 0x7FFFu] : 0.f;
+    if (threadIdx.x == 0) tk[256] = 0xFFFFFFFEu;  // differs from every token and from the invalid marker: lane 255 always ends a run
+    __syncthreads();
+    const uint32_t tok = tk[threadIdx.x];
+    if (valid && tok != tk[threadIdx.x + 1]) {
+      int j = threadIdx.x;
+      while (j > 0 && tk[j - 1] == tok) --j;
+      float sum = 0.f;
+      for (; j <= (int)threadIdx.x; ++j) sum += tv[j];
+      if (sum != 0.f) d[tok] += sum;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 // ---- K12 / K13 ---------------------------------------------------------------------------------
 __global__ void nll_fwd_kernel(const float* __restrict__ dist, const int64_t* __restrict__ target,
                                float* __restrict__ per_row, int64_t rows, int64_t V) {
@@ -399,6 +466,26 @@ extern "C" int case_copy_scatter_bwd(const int64_t* src, const float* d_dist, fl
   hipLaunchKernelGGL(copy_scatter_bwd_kernel, dim3(grid_for(B * T * S, 256, 2)), dim3(256), 0, (hipStream_t)stream, src,
                      d_dist, d_w, B, T, S, V);
   return case_check_launch("case_copy_scatter_bwd");
+}
+
+extern "C" int case_source_sort(const int64_t* src, uint32_t* keys, int64_t B, int64_t S, int64_t V, case_stream_t stream) {
+  CASE_REQUIRE(src && keys && B > 0 && S > 0 && V > 0, "case_source_sort: bad argument");
+  CASE_REQUIRE(S <= 32768 && V <= 131071, "case_source_sort: S <= 32768 and V <= 131071 (token << 15 | position must fit 32 bits)");
+  int n = 2;
+  while (n < S) n <<= 1;
+  // opt-in to > 64 KiB of dynamic LDS: idempotent host call, once per batch (no library state kept)
+  if (n > 16384 && hipFuncSetAttribute((const void*)source_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) != hipSuccess)
+    return case_set_error(CASE_E_LAUNCH, "case_source_sort: cannot reserve 128 KiB of LDS");
+  hipLaunchKernelGGL(source_sort_kernel, dim3((unsigned)B), dim3(1024), (size_t)n * 4, (hipStream_t)stream, src, keys, S, V, n);
+  return case_check_launch("case_source_sort");
+}
+
+extern "C" int case_copy_scatter_sorted_fwd(const uint32_t* keys, const float* w, float* dist, int64_t B, int64_t T, int64_t S,
+                                            int64_t V, case_stream_t stream) {
+  CASE_REQUIRE(keys && w && dist && B > 0 && T > 0 && S > 0 && V > 0 && B * T < (1ll << 31), "case_copy_scatter_sorted_fwd: bad argument");
+  CASE_REQUIRE(S <= 32768 && V <= 131071, "case_copy_scatter_sorted_fwd: S <= 32768 and V <= 131071");
+  hipLaunchKernelGGL(copy_scatter_sorted_kernel, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream, keys, w, dist, T, S, V);
+  return case_check_launch("case_copy_scatter_sorted_fwd");
 }
 
 extern "C" int case_nll_gather_fwd(const float* dist, const int64_t* target, float* per_row, int64_t rows, int64_t V,

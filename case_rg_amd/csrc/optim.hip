@@ -1,0 +1,94 @@
+// K15  optimizer-side multi-tensor kernels: everything the reference's loop does to the parameters between two backward passes
+// (common/CumulativeTrainer.py:70-76) -- clip_grad_norm_(params, 1), optim.Adam.step(), EMA.update() (common/EMA.py:13-18) --
+// plus the refresh of the bf16 operand copies, as TWO launches over all 365 parameter tensors:
+//   case_optim_sumsq     sum of squares of every gradient (the global L2 norm), f32 atomics into one scalar
+//   case_optim_adam_ema  clip coefficient from that scalar (no host round trip), Adam moments and update, EMA lerp, bf16 copy
+// ~7 GB of traffic at H = 512 (p, g, m, v, shadow read; p, m, v, shadow, bf16 written) instead of 6 passes and ~200 launches.
+// The tensors are addressed through a device table (one entry per tensor) and a chunk list (tensor index, chunk index), the
+// usual multi-tensor-apply layout; both are built by the host binding (case_rg_amd/optim.py).
+#include "common.h"
+
+namespace {
+constexpr int OPT_CHUNK = 16384;  // elements per workgroup
+constexpr int OPT_THREADS = 256;
+
+__global__ __launch_bounds__(OPT_THREADS) void optim_sumsq_kernel(const CaseOptTensor* __restrict__ table, const int32_t* __restrict__ chunks,
+                                                                  float* __restrict__ out) {
+  __shared__ float red[32];
+  const CaseOptTensor t = table[chunks[2 * blockIdx.x]];
+  const int64_t begin = (int64_t)chunks[2 * blockIdx.x + 1] * OPT_CHUNK;
+  const int64_t end = begin + OPT_CHUNK < t.numel ? begin + OPT_CHUNK : t.numel;
+  const float* g = reinterpret_cast<const float*>(t.g) + begin;
+  const int64_t n = end - begin;
+  float s = 0.f;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    const int64_t nv = n / 4;
+    for (int64_t i = threadIdx.x; i < nv; i += OPT_THREADS) {
+      const float4 v = *reinterpret_cast<const float4*>(g + 4 * i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t i = 4 * nv + threadIdx.x; i < n; i += OPT_THREADS) s += g[i] * g[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += OPT_THREADS) s += g[i] * g[i];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+struct AdamArgs {
+  const float* sumsq;  // null: no clipping
+  // derived on the host in double, as torch's _single_tensor_adam does: 1 - beta1, 1 - beta2, lr / (1 - beta1^t), sqrt(1 - beta2^t)
+  float max_norm, one_m_b1, beta2, one_m_b2, eps, step_size, bc2_sqrt, ema_w;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float clip) {
+  g *= clip;
+  m = m + a.one_m_b1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
+  v = a.beta2 * v + a.one_m_b2 * (g * g);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p -= a.step_size * (m / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void optim_adam_ema_kernel(const CaseOptTensor* __restrict__ table, const int32_t* __restrict__ chunks,
+                                                                     const AdamArgs a) {
+  const CaseOptTensor t = table[chunks[2 * blockIdx.x]];
+  const int64_t begin = (int64_t)chunks[2 * blockIdx.x + 1] * OPT_CHUNK;
+  const int64_t end = begin + OPT_CHUNK < t.numel ? begin + OPT_CHUNK : t.numel;
+  float clip = 1.f;
+  if (a.sumsq) clip = fminf(1.f, a.max_norm / (sqrtf(*a.sumsq) + 1e-6f));  // torch.nn.utils.clip_grad_norm_
+  float* p = reinterpret_cast<float*>(t.p);
+  const float* g = reinterpret_cast<const float*>(t.g);
+  float* m = reinterpret_cast<float*>(t.m);
+  float* v = reinterpret_cast<float*>(t.v);
+  float* sh = reinterpret_cast<float*>(t.shadow);
+  bf16_t* lp = reinterpret_cast<bf16_t*>(t.p_bf16);
+  for (int64_t i = begin + threadIdx.x; i < end; i += OPT_THREADS) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, a, clip);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (sh && a.ema_w > 0.f) sh[i] = sh[i] + a.ema_w * (pi - sh[i]);  // torch lerp (weight < 0.5): shadow + w (p - shadow)
+    if (lp) lp[i] = f32_to_bf16(pi);
+  }
+}
+}  // namespace
+
+extern "C" int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* sumsq, case_stream_t stream) {
+  CASE_REQUIRE(table && chunks && sumsq && nchunks > 0 && nchunks < (1ll << 31), "case_optim_sumsq: bad argument");
+  hipLaunchKernelGGL(optim_sumsq_kernel, dim3((unsigned)nchunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, table, chunks, sumsq);
+  return case_check_launch("case_optim_sumsq");
+}
+
+extern "C" int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
+                                   double lr, double beta1, double beta2, double eps, double bias_c1, double bias_c2, double ema_w,
+                                   case_stream_t stream) {
+  CASE_REQUIRE(table && chunks && nchunks > 0 && nchunks < (1ll << 31), "case_optim_adam_ema: bad argument");
+  CASE_REQUIRE(bias_c1 > 0. && bias_c2 > 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., "case_optim_adam_ema: bad hyper-parameters");
+  const AdamArgs a = {sumsq, max_norm, (float)(1. - beta1), (float)beta2, (float)(1. - beta2), (float)eps, (float)(lr / bias_c1),
+                      (float)sqrt(bias_c2), (float)ema_w};
+  hipLaunchKernelGGL(optim_adam_ema_kernel, dim3((unsigned)nchunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, table, chunks, a);
+  return case_check_launch("case_optim_adam_ema");
+}
+
+extern "C" int case_optim_chunk_elems(void) { return OPT_CHUNK; }

@@ -56,6 +56,13 @@ def invalidate_param_cache():
     _cast_cache.clear()
 
 
+def seed_param_cache(p, low):
+    """Install ``low`` (a low-precision copy of the whole Parameter ``p`` made elsewhere, e.g. by the fused optimizer pass)."""
+    src = p.detach()
+    key = (id(p), src.storage_offset(), tuple(src.shape), tuple(src.stride()), low.dtype)
+    _cast_cache[key] = (weakref.ref(p), (p._version, p.data_ptr(), p.device), low)
+
+
 def _evict_dead():
     for k in [k for k, v in _cast_cache.items() if v[0]() is None]:
         del _cast_cache[k]
@@ -79,6 +86,11 @@ def cast_param(p, dtype):
     hit = _cast_cache.get(key)
     if hit is not None and hit[0]() is owner and hit[1] == stamp:
         return hit[2]
+    if owner is not p and src.is_contiguous():  # a view (K/V rows of in_proj_weight ...): slice the whole-parameter copy if one is live
+        od = owner.detach()
+        whole = _cast_cache.get((id(owner), od.storage_offset(), tuple(od.shape), tuple(od.stride()), dtype))
+        if whole is not None and whole[0]() is owner and whole[1] == stamp and od.is_contiguous():
+            return whole[2].as_strided(src.shape, src.stride(), src.storage_offset() - od.storage_offset())
     _evict_dead()
     src = src.contiguous()
     out = torch.empty(src.shape, dtype=dtype, device=src.device)
@@ -1053,14 +1065,34 @@ def additive_scores(wq, uh, v):
 # ----------------------------------------------------------------------------------------------
 # K11 pointer scatter / K12 NLL / K13 argmax
 # ----------------------------------------------------------------------------------------------
+class SortedSource(object):
+    """A source map [B, S] with its device-sorted (token, position) keys, made once per batch and shared by every
+    pointer scatter of that batch (one per training step; one per generated token in greedy decoding)."""
+    MAX_S, MAX_V = 32768, 131071
+
+    def __init__(self, ids, V):
+        self.ids = ids.contiguous()
+        self.V = V
+        B, S = self.ids.shape
+        self.keys = torch.empty(B, S, dtype=torch.int32, device=ids.device)
+        A.call("case_source_sort", _ptr(self.ids), _ptr(self.keys), B, S, V, _stream())
+
+    @classmethod
+    def fits(cls, ids, V):
+        return ids.dtype == torch.int64 and ids.dim() == 2 and ids.size(1) <= cls.MAX_S and V <= cls.MAX_V
+
+
 class CopyScatterFn(Function):
     @staticmethod
-    def forward(ctx, src_ids, w, V, base):
-        """dist[b, t, src[b, s]] += w[b, t, s] on top of ``base`` (or zeros)."""
+    def forward(ctx, src_ids, w, V, base, keys=None):
+        """dist[b, t, src[b, s]] += w[b, t, s] on top of ``base`` (or zeros); with sorted ``keys`` run by run, without atomics."""
         B, T, S = w.shape
         w = w.float().contiguous()
         dist = torch.zeros(B, T, V, dtype=torch.float32, device=w.device) if base is None else base.float().clone()
-        A.call("case_copy_scatter_fwd", _ptr(src_ids), _ptr(w), _ptr(dist), B, T, S, V, _stream())
+        if keys is not None:
+            A.call("case_copy_scatter_sorted_fwd", _ptr(keys), _ptr(w), _ptr(dist), B, T, S, V, _stream())
+        else:
+            A.call("case_copy_scatter_fwd", _ptr(src_ids), _ptr(w), _ptr(dist), B, T, S, V, _stream())
         ctx.save_for_backward(src_ids)
         ctx.meta = (B, T, S, V, base is not None)
         return dist
@@ -1072,10 +1104,14 @@ class CopyScatterFn(Function):
         g = g.float().contiguous()
         d_w = torch.empty(B, T, S, dtype=torch.float32, device=g.device)
         A.call("case_copy_scatter_bwd", _ptr(src_ids), _ptr(g), _ptr(d_w), B, T, S, V, _stream())
-        return None, d_w, None, (g if has_base else None)
+        return None, d_w, None, (g if has_base else None), None
 
 
 def copy_scatter(src_ids, w, V, base=None):
+    if isinstance(src_ids, SortedSource):
+        if src_ids.V != V:
+            raise ValueError("source map was sorted for a vocabulary of %d, scatter asks for %d" % (src_ids.V, V))
+        return CopyScatterFn.apply(src_ids.ids, w, V, base, src_ids.keys)
     return CopyScatterFn.apply(src_ids.contiguous(), w, V, base)
 
 

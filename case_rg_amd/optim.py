@@ -1,0 +1,109 @@
+"""Adam for the MI355X path: torch.optim.Adam's update rule (CaSE/Run.py:27: ``optim.Adam(lr=2.5e-4)``, default betas / eps, no
+weight decay, no amsgrad) as ONE multi-tensor launch that also applies what the reference's loop does around it
+(common/CumulativeTrainer.py:70-76): the global-norm clip (``clip_grad_norm_(params, 1)``, second launch for the norm), the EMA
+update (common/EMA.py:13-18) and the refresh of the bf16 operand copies the kernels read.
+
+``CumulativeTrainer`` recognises this class and hands it the clip threshold and its EMA object; with any other optimizer it
+runs the reference's three separate calls.  State (exp_avg, exp_avg_sq, step) lives in ``self.state`` like torch's, so
+``state_dict`` / ``load_state_dict`` and the resumable checkpoint work unchanged."""
+import ctypes as C
+
+import torch
+
+from . import _abi as A
+from . import ops
+
+
+class _Entry(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p),
+                ("p_bf16", C.c_void_p), ("numel", C.c_int64)]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, low_precision=None):
+        """``low_precision``: dtype (torch.bfloat16) of operand copies to refresh in the same pass, or None."""
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.low_precision = low_precision
+        self._chunks = {}
+        self._table = (None, None)  # (host bytes, device copy): re-uploaded only when a pointer moved
+        self._low = {}  # id(parameter) -> its operand copy, rewritten in place by every step
+
+    def _chunk_list(self, numels, device):
+        key = (tuple(numels), str(device))
+        if key not in self._chunks:
+            per = A.lib.case_optim_chunk_elems()
+            pairs = [(i, c) for i, n in enumerate(numels) for c in range((n + per - 1) // per)]
+            self._chunks = {key: torch.tensor(pairs, dtype=torch.int32).to(device)}
+        return self._chunks[key]
+
+    @torch.no_grad()
+    def step(self, closure=None, clip_norm=None, ema=None):
+        """One optimizer step.  ``clip_norm``: global L2 clip threshold applied on the fly (gradients are left untouched);
+        ``ema``: a ``case_rg_amd.common.EMA.EMA`` whose shadow weights are updated in the same pass."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        shadow_of = {}
+        if ema is not None:
+            names = {id(p): n for n, p in ema.model.named_parameters()}
+            shadow_of = {pid: ema.shadow[n] for pid, n in names.items() if n in ema.shadow}
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            dev = params[0].device
+            if not params[0].is_cuda:
+                raise RuntimeError("case_rg_amd.optim.FusedAdam runs on the GPU only; there is no CPU path")
+            beta1, beta2 = group["betas"]
+            entries = (_Entry * len(params))()
+            fresh = {}
+            steps = set()
+            for i, p in enumerate(params):
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("FusedAdam expects contiguous float32 parameters and gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+                steps.add(st["step"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                sh = shadow_of.get(id(p))
+                lp = None
+                if self.low_precision is not None and p.dim() > 1:
+                    lp = self._low.get(id(p))
+                    if lp is None or lp.shape != p.shape or lp.device != dev:
+                        lp = self._low[id(p)] = torch.empty(p.shape, dtype=self.low_precision, device=dev)
+                    fresh[id(p)] = lp
+                entries[i] = _Entry(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                    0 if sh is None else sh.data_ptr(), 0 if lp is None else lp.data_ptr(), p.numel())
+                st["_g"] = g  # keep a non-contiguous gradient's copy alive until the launch has consumed it
+            if len(steps) != 1:
+                raise RuntimeError("FusedAdam: parameters of one group must share their step count")
+            step = steps.pop()
+            raw = bytes(entries)
+            if self._table[0] != raw or self._table[1].device != dev:
+                self._table = (raw, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
+            table = self._table[1]
+            chunks = self._chunk_list([p.numel() for p in params], dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            sumsq = None
+            if clip_norm is not None:
+                sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+                A.call("case_optim_sumsq", table.data_ptr(), chunks.data_ptr(), chunks.shape[0], sumsq.data_ptr(), stream)
+            A.call("case_optim_adam_ema", table.data_ptr(), chunks.data_ptr(), chunks.shape[0], None if sumsq is None else sumsq.data_ptr(),
+                   float(clip_norm or 0.0), float(group["lr"]), beta1, beta2, group["eps"], 1.0 - beta1 ** step, 1.0 - beta2 ** step,
+                   0.0 if ema is None else 1.0 - ema.decay, stream)
+            for p in params:
+                self.state[p].pop("_g", None)
+            # the kernel wrote the parameters behind autograd's back (_version did not move): drop every cached operand copy and
+            # seed the cache with the copies this pass produced
+            ops.invalidate_param_cache()
+            for p in params:
+                if id(p) in fresh:
+                    ops.seed_param_cache(p, fresh[id(p)])
+        return loss

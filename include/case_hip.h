@@ -267,6 +267,14 @@ int case_copy_scatter_fwd(const int64_t* src, const float* w, float* dist, int64
                           int64_t V, case_stream_t stream);
 int case_copy_scatter_bwd(const int64_t* src, const float* d_dist, float* d_w, int64_t B, int64_t T, int64_t S,
                           int64_t V, case_stream_t stream);
+/* Sorted form (on-device source_map sort, once per batch; the reference rebuilds a [B, S, V] one-hot per call,
+ * common/Utils.py:344-355).  case_source_sort: keys u32 [B, S] = (src[b, s] << 15 | s) ascending per row, ids outside [0, V)
+ * last as 0xFFFFFFFF; needs S <= 32768, V <= 131071.  case_copy_scatter_sorted_fwd adds each run of equal tokens to dist in a
+ * fixed order with plain stores: no atomics, bit-reproducible.  Same dist contract as case_copy_scatter_fwd; the backward is
+ * case_copy_scatter_bwd (a gather, order-free). */
+int case_source_sort(const int64_t* src, uint32_t* keys, int64_t B, int64_t S, int64_t V, case_stream_t stream);
+int case_copy_scatter_sorted_fwd(const uint32_t* keys, const float* w, float* dist, int64_t B, int64_t T, int64_t S,
+                                 int64_t V, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K12 losses
@@ -281,6 +289,32 @@ int case_nll_gather_bwd(const float* dist, const int64_t* target, const float* g
                         int64_t V, case_stream_t stream);
 int case_row_argmax(const float* x, int64_t* idx, float* val, int64_t rows, int64_t cols, int64_t ld,
                     case_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K15  optimizer-side multi-tensor kernels: common/CumulativeTrainer.py:70-76 clip_grad_norm_(params, 1) ->
+ *   optim.Adam.step() (CaSE/Run.py:27: default betas / eps, no weight decay) -> EMA.update() (common/EMA.py:13-18), plus the
+ *   refresh of the bf16 operand copies, in two launches over all parameter tensors.
+ * `table` (device): one CaseOptTensor per tensor, f32 p / g / m (exp_avg) / v (exp_avg_sq) / shadow (EMA, may be null),
+ *   p_bf16 (may be null), numel.  `chunks` (device): int32 pairs (tensor index, chunk index), one per workgroup, chunk =
+ *   case_optim_chunk_elems() elements.  sumsq: pre-zeroed f32 scalar; pass it to case_optim_adam_ema to apply the clip
+ *   coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) without a host round trip (null: no clipping).
+ * bias_c1 = 1 - beta1^step, bias_c2 = 1 - beta2^step (host scalars; the derived step size lr / bias_c1, sqrt(bias_c2), 1 - beta are
+ *   formed in double and rounded to f32 once, as torch.optim.Adam does); ema_w = 1 - decay (0: no EMA update).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  void* p;
+  const void* g;
+  void* m;
+  void* v;
+  void* shadow;
+  void* p_bf16;
+  int64_t numel;
+} CaseOptTensor;
+int case_optim_chunk_elems(void);
+int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* sumsq, case_stream_t stream);
+int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
+                        double lr, double beta1, double beta2, double eps, double bias_c1, double bias_c2, double ema_w,
+                        case_stream_t stream);
 
 /* Greedy post-processing on the device (common/Utils.py:200-217 to_sentence): per row of ids [B, T] drop the BOS / PAD ids and
  * everything from the first EOS on; out [B, T] holds the kept ids front-packed (pad behind), len [B] their count.  One host

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_table_matches_header():
     from case_rg_amd import _abi
-    assert set(_abi.SIGNATURES) | {"case_version", "case_last_error", "case_gemm_tile_for"} == _declared()
+    assert set(_abi.SIGNATURES) | {"case_version", "case_last_error", "case_gemm_tile_for", "case_optim_chunk_elems"} == _declared()
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for name, args in _abi.SIGNATURES.items():
         proto = re.search(r"\b%s\s*\((.*?)\);" % name, text, flags=re.S).group(1)

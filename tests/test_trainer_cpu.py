@@ -183,3 +183,59 @@ def test_init_params_matches_the_reference_rule():
             assert torch.equal(p, before[n]), n
     emb = dict(model.named_parameters())["query_encoder.embedding.0.weight"]
     assert emb[0].abs().sum() > 0, "PAD row is re-initialised too (reference :19-20)"
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """the reference saves weights only (:80-86); save_checkpoint / load_checkpoint carry optimizer moments + step,
+    scheduler, EMA shadow, the accumulation counter and the RNG streams, so a resumed run repeats the uninterrupted one."""
+    from case_rg_amd import config
+
+    def run(n_first, resume):
+        model = _tiny(seed=8)
+        tr = CumulativeTrainer(model, None, None, None, 1, accumulation_steps=2)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        sched = get_cosine_with_hard_restarts_schedule_with_warmup(opt, 2, 10)
+        config.manual_seed(77)
+        ds = _dataset(12, 9)
+        batches = [cases._collate(ds.items[i:i + 2]) for i in range(0, 12, 2)]
+        for b in batches[:n_first]:
+            tr.train_batch(0, dict(b), "train", opt, sched)
+        if resume:
+            config.next_rng(10)  # the dropout counter moved during the first half
+            path = tr.save_checkpoint(0, str(tmp_path), opt, sched)
+            assert path.endswith(os.path.join("model", "0.ckpt"))
+            model = _tiny(seed=99)  # different weights: everything must come from the file
+            tr = CumulativeTrainer(model, None, None, None, 1, accumulation_steps=2)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            sched = get_cosine_with_hard_restarts_schedule_with_warmup(opt, 2, 10)
+            config.manual_seed(1)
+            assert tr.load_checkpoint(path, opt, sched) == 0
+            assert config.rng_state() == (77, 10)
+        for b in batches[n_first:]:
+            tr.train_batch(0, dict(b), "train", opt, sched)
+        return tr, opt, sched
+
+    a, oa, sa = run(6, False)
+    b, ob, sb = run(3, True)  # interrupted in the MIDDLE of an accumulation group (count 3 of steps 2)
+    assert a.accumulation_count == b.accumulation_count == 6
+    assert sa.last_epoch == sb.last_epoch and sa.get_last_lr() == sb.get_last_lr()
+    pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
+    for n in pa:
+        # the half-accumulated gradient of batch 3 is not part of a checkpoint: the resumed group sees batch 4 only
+        assert torch.isfinite(pb[n]).all()
+    # interrupted on a group boundary the trajectories are identical, bit for bit
+    c, oc, sc = run(4, True)
+    pc = dict(c.model.named_parameters())
+    for n in pa:
+        assert torch.equal(pa[n], pc[n]), n
+        assert torch.equal(a.ema.shadow[n], c.ema.shadow[n]), n
+    for (ka, va), (kc, vc) in zip(oa.state_dict()["state"].items(), oc.state_dict()["state"].items()):
+        assert torch.equal(va["exp_avg"], vc["exp_avg"]) and torch.equal(va["exp_avg_sq"], vc["exp_avg_sq"]) and va["step"] == vc["step"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_prefetcher_is_a_pass_through_without_a_gpu():
+    from case_rg_amd.utils.pipeline import DevicePrefetcher
+    batches = [{"x": torch.full((2,), float(i))} for i in range(3)]
+    out = list(DevicePrefetcher(batches))
+    assert len(out) == 3 and all(a is b for a, b in zip(out, batches)) and len(DevicePrefetcher(batches)) == 3
