@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  -- first: libcase_hip.so must bind to the HIP runtime instance torch has already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcase_hip.so")
+# CASE_HIP_LIB: another build of the same library (A/B measurements of kernel variants); there is still no non-HIP path
+LIB_PATH = os.environ.get("CASE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcase_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8

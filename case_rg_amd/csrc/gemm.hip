@@ -48,6 +48,7 @@ struct Args {
 #undef GEMM_NTHREADS
 
 #include "gemm256.inc"
+#include "gemm8w.inc"
 
 namespace {
 constexpr int BM = 128, BN = 128, ROWB = 128;
@@ -129,7 +130,10 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
       a.vec_a && a.vec_b && a.vec_c && d->lda < (1 << 22) && d->ldb < (1 << 22) && d->ldc < (1 << 22) && d->ld_aux < (1 << 22) &&
       (!(epi & CASE_EPI_ATOMIC) || (epi == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32))) {
     const int64_t t256 = (d->M / 256) * (d->N / 256) * a.split_k;
-    if (d->tile == 256 || gemm_t256::prefer(nwg, t256, device_cus())) *tile = 256;
+    // k-major operands advance by 64 leading-dimension rows per K tile through a 32-bit DMA offset
+    const bool span_ok = (!d->a_kmajor || (d->K / a.split_k + 64) * d->lda < (1ll << 30)) &&
+                         (!d->b_kmajor || (d->K / a.split_k + 64) * d->ldb < (1ll << 30));
+    if (span_ok && (d->tile == 256 || gemm_t8w::prefer(nwg, t256, device_cus()))) *tile = 256;
   }
   return 0;
 }
@@ -155,9 +159,9 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
   hipStream_t s = (hipStream_t)stream;
   if (tile == 256) {
     const int cus = device_cus();
-    if (d->out_dtype == CASE_BF16) return gemm_t256::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-    if (epi & CASE_EPI_ATOMIC) return gemm_t256::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-    return gemm_t256::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    if (d->out_dtype == CASE_BF16) return gemm_t8w::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    if (epi & CASE_EPI_ATOMIC) return gemm_t8w::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    return gemm_t8w::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
   }
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return gemm_w4::launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return gemm_w4::launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);
