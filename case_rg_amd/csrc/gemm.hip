@@ -47,7 +47,6 @@ struct Args {
 #undef GEMM_NS
 #undef GEMM_NTHREADS
 
-#include "gemm256.inc"
 #include "gemm8w.inc"
 
 namespace {

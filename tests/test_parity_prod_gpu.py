@@ -7,7 +7,7 @@ S = 20 480) were captured from the reference itself (tests/golden/gen_golden.py)
   bf16_large_fused    bf16, 256x256 GEMM tiling wherever eligible, fused attention forward wherever built
   bf16_small_unfused  bf16, 128x128 GEMM tiling only, GEMM + softmax + GEMM attention
 
-so ``gemm256_kernel``, ``fa_fwd`` / ``fa_bwd_*`` and the vector softmax run inside a test whose expected values came from the
+so ``gemm8w_kernel``, ``fa_fwd`` / ``fa_bwd_*`` and the vector softmax run inside a test whose expected values came from the
 reference.  Every comparison's measured error goes to gpurun_out/parity_errors.json (committed per round under profiles/).
 
 bf16 bars are set from those measurements (1.5-2x the worst observed, profiles/r02_parity_errors.json), per kind of tensor:
@@ -106,7 +106,7 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
     if mode == "bf16_small_unfused":
         assert 256 not in m.tiles and m.calls.get("case_attention_fwd", 0) == 0
     if mode == "bf16_auto" and name.endswith("_train"):
-        assert 256 in m.tiles and m.calls.get("case_attention_bwd", 0) > 0, "bench-mode kernels (gemm256, fa_bwd) did not run"
+        assert 256 in m.tiles and m.calls.get("case_attention_bwd", 0) > 0, "bench-mode kernels (gemm8w, fa_bwd) did not run"
 
 
 def test_bf16_block_gradient_error_is_the_relu_mask():

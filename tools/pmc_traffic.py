@@ -18,9 +18,9 @@ import sys
 
 def family(name):
     """C++ kernel name -> the family key bench.py prints."""
-    m = re.search(r"gemm256_kernel<(unsigned short|float), (true|false), (true|false), (true|false)>", name)
+    m = re.search(r"gemm8w_kernel<(unsigned short|float), (true|false), (true|false), (true|false)>", name)
     if m:
-        return "gemm256_kernel<bf16,%s,%s,%s>" % ("bf16" if m.group(1) == "unsigned short" else "f32",
+        return "gemm8w_kernel<bf16,%s,%s,%s>" % ("bf16" if m.group(1) == "unsigned short" else "f32",
                                                     "Ak" if m.group(2) == "true" else "A", "Bk" if m.group(3) == "true" else "B")
     m = re.search(r"gemm_kernel<(unsigned short|float), (unsigned short|float), (true|false), (true|false), (true|false)>", name)
     if m:
