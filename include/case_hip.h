@@ -89,7 +89,7 @@ int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, cons
               const float* bias_row, const void* aux, void* aux_out, case_stream_t stream);
 
 /* case_gemm owns two tilings: 128x128 (every shape / dtype / batch) and 256x256 (bf16, M % 256 == N % 256 == 0,
- * K % 64 == 0, unbatched, 16-byte aligned; accumulators in AGPRs, persistent).  CaseGemmDesc.tile selects per call; results
+ * K % 64 == 0, unbatched, 16-byte aligned; eight waves, operands by LDS-DMA, persistent: csrc/gemm8w.inc).  CaseGemmDesc.tile selects per call; results
  * of the two tilings agree to f32 summation order.  case_gemm_tile_for() returns the tile edge (128 or 256) case_gemm would
  * launch for exactly these arguments (or a negative CASE_E_* code): a pure function of its arguments, no launch, no state --
  * bench.py uses it to attribute each launch to the kernel name rocprofv3 reports. */
