@@ -39,6 +39,7 @@ class AttnDesc(C.Structure):
 # name -> argument types (all return int); mirrors include/case_hip.h one to one
 SIGNATURES = {
     "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_gemm_dw_bias": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr],
     "case_embed_pos_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
     "case_embed_pos_bwd": [ptr, ptr, ptr, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
     "case_scale_add_rows": [ptr, ptr, ptr, i64, i64, i64, f32, i32, ptr],

@@ -36,6 +36,7 @@ struct Args {
   uint64_t seed, offset;
   int vec_a, vec_b;  // 16-byte global loads are legal for the operand
   int vec_c;         // 16-byte accesses are legal for C / aux / aux_out / bias_col
+  float* rowsum;     // case_gemm_dw_bias: pre-zeroed f32 [M], receives sum_k op(A)[m, k] (the bias gradient of a weight-gradient GEMM)
 };
 
 // The kernel body is parameterised by the workgroup size (gemm_impl.inc): 256 threads = 4 waves x (64x64) per 128x128
@@ -108,6 +109,7 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
   CASE_REQUIRE(nwg < (1ll << 31), "case_gemm: grid too large");
   a.nwg = (int)nwg;
   a.alpha = d->alpha;
+  a.rowsum = nullptr;
   a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
   // 16-byte loads need the contiguous extent, every leading stride and the base to be 16-byte multiples
   auto aligned = [&](const void* p, int64_t ld, int64_t s1, int64_t s2, int64_t extent) {
@@ -146,6 +148,19 @@ extern "C" int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const vo
   const int rc = prepare(d, A, B, const_cast<void*>(C), bias_col, (d && (d->epilogue & CASE_EPI_BIAS_ROW)) ? &one : nullptr, aux,
                          const_cast<void*>(aux_out), a, &tile);
   return rc ? rc : tile;
+}
+
+extern "C" int case_gemm_dw_bias(const CaseGemmDesc* d, const void* A, const void* B, void* C, float* d_bias, case_stream_t stream) {
+  Args a;
+  int tile = 0;
+  const int rc = prepare(d, A, B, C, nullptr, nullptr, nullptr, nullptr, a, &tile);
+  if (rc) return rc;
+  CASE_REQUIRE(d_bias, "case_gemm_dw_bias: null d_bias");
+  if (!(tile == 256 && d->a_kmajor && d->epilogue == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32))
+    return case_set_error(CASE_E_UNSUPPORTED, "case_gemm_dw_bias: needs the 256x256 tiling (see case_gemm_tile_for), a k-major A, "
+                                              "the bare ATOMIC epilogue and f32 output");
+  a.rowsum = d_bias;
+  return gemm_t8w::launch<float, true>(a, d->epilogue, d->a_kmajor, d->b_kmajor, device_cus(), (hipStream_t)stream);
 }
 
 extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,

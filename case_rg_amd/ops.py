@@ -116,11 +116,15 @@ def cast(x, dtype):
 GEMM_TILE = 0
 # Measurement aid (bench.py): when a list, every launch appends the tile edge case_gemm_tile_for() reports for it.
 TILE_TRACE = None
+# Bias gradients of the weight-gradient GEMMs inside the same launch (False: always the separate column-sum pass; A/B measurements)
+FUSE_BIAS_GRAD = True
 
 
 def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          batch1=1, batch2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, epilogue=0, bias_col=None, bias_row=None,
-         aux=None, aux_out=None, ld_aux=0, saux=(0, 0), split_k=1, drop=None):
+         aux=None, aux_out=None, ld_aux=0, saux=(0, 0), split_k=1, drop=None, rowsum_out=None):
+    """``rowsum_out`` (weight-gradient calls: k-major contiguous A, ATOMIC epilogue): pre-zeroed f32 [M] that also receives
+    sum_k op(A)[m, k], the bias gradient -- inside the same launch when the 256x256 tiling takes the call, else by case_colsum."""
     d = A.GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ld_aux = M, N, K, lda, ldb, ldc, ld_aux
     d.batch1, d.batch2 = batch1, batch2
@@ -146,6 +150,13 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
     if TILE_TRACE is not None:
         TILE_TRACE.append(A.lib.case_gemm_tile_for(d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(aux),
                                                    _ptr(aux_out)))
+    if rowsum_out is not None:
+        if not (a_kmajor and epilogue == A.EPI_ATOMIC and lda == M and batch1 * batch2 == 1 and a_off == 0):
+            raise ValueError("rowsum_out needs an unbatched k-major contiguous A and the bare ATOMIC epilogue")
+        if FUSE_BIAS_GRAD and a.dtype == torch.bfloat16 and A.lib.case_gemm_tile_for(d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), None, None, None) == 256:
+            A.call("case_gemm_dw_bias", d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), _ptr(rowsum_out), _stream())
+            return c
+        A.call("case_colsum", _ptr(a), _ptr(rowsum_out), K, M, _code(a), _stream())
     A.call("case_gemm", d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(bias_row), _ptr(aux),
            _ptr(aux_out), _stream())
     return c
@@ -199,12 +210,13 @@ def _zeros_like_shapes(device, *shapes):
     return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
-def _weight_grad(g2, x2, N, K, out=None):
-    """dW[N, K] = g2[M, N]^T x2[M, K]  (both operands k-major, f32 atomics across K splits); ``out`` is pre-zeroed."""
+def _weight_grad(g2, x2, N, K, out=None, bias_out=None):
+    """dW[N, K] = g2[M, N]^T x2[M, K]  (both operands k-major, f32 atomics across K splits); ``out`` is pre-zeroed.
+    ``bias_out`` (pre-zeroed f32 [N]) also receives the bias gradient, the column sums of g2 (see ``gemm(rowsum_out=)``)."""
     M = g2.shape[0]
     dw = out if out is not None else torch.zeros(N, K, dtype=torch.float32, device=g2.device)
     split = _split_for(N, K, M, g2.element_size())
-    gemm(g2, x2, dw, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC)
+    gemm(g2, x2, dw, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC, rowsum_out=bias_out)
     return dw
 
 
@@ -297,8 +309,7 @@ class LinearFn(Function):
         want_w, want_b = ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
         if want_w and want_b:
             dw, db = _zeros_like_shapes(g.device, (N, K), (N,))
-            _weight_grad(g, x2, N, K, out=dw)
-            _colsum(g, out=db)
+            _weight_grad(g, x2, N, K, out=dw, bias_out=db)
         elif want_w:
             dw = _weight_grad(g, x2, N, K)
         elif want_b:
@@ -395,16 +406,14 @@ class FFNFn(Function):
         if drop_o is not None:
             g = _dropout_raw(g, *drop_o)
         dw1, db1, dw2, db2 = _zeros_like_shapes(g.device, (F_, K), (F_,), (N, F_), (N,))
-        _weight_grad(g, a, N, F_, out=dw2)
-        _colsum(g, out=db2)
+        _weight_grad(g, a, N, F_, out=dw2, bias_out=db2)
         # dz = (g W2) * act'(.) * keep_i/(1-p_i): one GEMM with the derivative (and the regenerated mask) in the epilogue
         dz = torch.empty(M, F_, dtype=x2.dtype, device=x2.device)
         if act == "gelu":
             gemm(g, w2c, dz, M, F_, N, N, F_, F_, b_kmajor=True, epilogue=A.EPI_MUL_DGELU, aux=z, ld_aux=F_, drop=drop_i)
         else:
             gemm(g, w2c, dz, M, F_, N, N, F_, F_, b_kmajor=True, epilogue=A.EPI_MUL_DRELU, aux=a, ld_aux=F_, drop=drop_i)
-        _weight_grad(dz, x2, F_, K, out=dw1)
-        _colsum(dz, out=db1)
+        _weight_grad(dz, x2, F_, K, out=dw1, bias_out=db1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)

@@ -93,6 +93,12 @@ int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, cons
  * of the two tilings agree to f32 summation order.  case_gemm_tile_for() returns the tile edge (128 or 256) case_gemm would
  * launch for exactly these arguments (or a negative CASE_E_* code): a pure function of its arguments, no launch, no state --
  * bench.py uses it to attribute each launch to the kernel name rocprofv3 reports. */
+/* Weight-gradient GEMM that also produces the bias gradient (replaces a separate pass over dY, case_colsum; reference:
+ * autograd of nn.Linear, e.g. common/TransformerBlock.py:13-14): C[M, N] += op(A) op(B) as case_gemm with the bare ATOMIC epilogue,
+ * and d_bias[m] += sum_k op(A)[m, k] (f32 [M], pre-zeroed, atomics).  Only for calls the 256x256 tiling takes with a k-major A
+ * (case_gemm_tile_for(...) == 256, d->a_kmajor): CASE_E_UNSUPPORTED otherwise, and the caller runs case_gemm + case_colsum. */
+int case_gemm_dw_bias(const CaseGemmDesc* d, const void* A, const void* B, void* C, float* d_bias, case_stream_t stream);
+
 int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const void* B, const void* C, const float* bias_col,
                        const void* aux, const void* aux_out);
 

@@ -585,6 +585,24 @@ def test_gemm_large_tile_epilogues_and_persistence():
     _close(large, small.float(), 1e-2, "persistent: tilings agree")
 
 
+def test_weight_gradient_gemm_also_sums_the_bias_gradient():
+    """case_gemm_dw_bias: dW = dY^T X with the bias gradient (column sums of dY) taken from the k-major A fragments of the same
+    launch (256x256 tiling), and the fallback (separate column-sum pass) for calls the large tiling does not take."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    dt = torch.bfloat16
+    for (Mtok, N, K, split) in ((64 * 24, 512, 256, 3), (64 * 40, 768, 512, 5), (64 * 7, 256, 256, 1), (64 * 9, 320, 256, 2)):
+        g, x = _rand(Mtok, N, dt=dt, seed=1), _rand(Mtok, K, dt=dt, seed=2, scale=Mtok ** -0.5)
+        dw = torch.zeros(N, K, device="cuda", dtype=torch.float32)
+        db = torch.zeros(N, device="cuda", dtype=torch.float32)
+        ops.gemm(g, x, dw, N, K, Mtok, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC, rowsum_out=db)
+        torch.cuda.synchronize()
+        _close(dw, g.float().t() @ x.float(), 2e-3, "dW with fused bias gradient N=%d" % N)
+        _close(db, g.float().sum(0), 2e-3, "bias gradient N=%d (fused on the 256 tiling: %s)" % (N, N % 256 == 0))
+    with pytest.raises(ValueError):
+        ops.gemm(g, x, dw, 320, 256, 576, 320, 256, 256, b_kmajor=True, epilogue=A.EPI_ATOMIC, rowsum_out=db)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("T", [1, 2])
 def test_additive_scores_decode_rows(dt, T):

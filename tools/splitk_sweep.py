@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Split-K sweep of the weight-gradient GEMM (TN, f32 atomics) on the 128x128 and the 256x256 tiling."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from case_rg_amd import ops
+from case_rg_amd import _abi as A
+
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+dt = torch.bfloat16
+Mtok = 122880
+for (N, K) in [(512, 512), (1536, 512), (512, 2560), (2560, 2560)]:
+    g = torch.randn(Mtok, N, device="cuda").to(dt)
+    x = torch.randn(Mtok, K, device="cuda").to(dt)
+    dw = torch.zeros(N, K, device="cuda", dtype=torch.float32)
+    cur = ops._split_for(N, K, Mtok, 2)
+    for tile in (128, 256):
+        ops.GEMM_TILE = tile
+        row = []
+        for split in (4, 8, 12, 16, 24, 32, 48, 64):
+            ms = timeit(lambda: ops.gemm(g, x, dw, N, K, Mtok, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC))
+            row.append("%d:%.3f" % (split, ms))
+        print("dW %dx%d tile %d (heuristic split %d)  ms by split: %s" % (N, K, tile, cur, "  ".join(row)), flush=True)
+    ops.GEMM_TILE = 0
