@@ -50,7 +50,9 @@ class CumulativeTrainer(object):
         self.model = model.cuda() if torch.cuda.is_available() else model
         self.accumulation_steps = accumulation_steps
         self.accumulation_count = 0
-        self.sync = GradSync(self.model) if dist.is_available() and dist.is_initialized() else None
+        # CASE_FORCE_GRADSYNC: keep the bucket / hook / collective machinery live on a one-rank group (one-GPU rehearsal of the DP path)
+        self.sync = (GradSync(self.model, force=bool(os.environ.get("CASE_FORCE_GRADSYNC")))
+                     if dist.is_available() and dist.is_initialized() else None)
         self.ema = EMA(self.model, ema_rate)
         self.ema.register()
 
