@@ -52,6 +52,8 @@ SIGNATURES = {
     "case_attention_splitkv_workspace": [C.POINTER(AttnDesc), i32, C.POINTER(i64)],
     "case_attention_fwd_splitkv": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "case_attention_bwd_supported": [i64],
+    "case_attention_decode_supported": [i64],
+    "case_attention_decode": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr],
     "case_attention_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],
     "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],

@@ -956,3 +956,156 @@ extern "C" int case_attention_bwd(const CaseAttnDesc* d, const void* q, const vo
     default: return launch_bwd<480>(a, g, (const bf16_t*)out, delta, s);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Decode step (one query per sequence): HBM-bound K / V streaming, no MFMA.
+// CaSE greedy decoding attends ONE new position per step to the cached projections of the memories (cross-attention: 3840 keys
+// per item at cfg 4, 31.5 MB per item and step over the four layers -- SURVEY 8d) and to the <= T cached positions of the answer.
+// One workgroup per (sequence, head); a key row of head_dim 64 is 128 bytes = 8 lanes x 16 B, so a wave-instruction brings in 8
+// keys as full 128-byte lines; each 8-lane group keeps its own online-softmax state (base-2 domain) and 8 output dims per lane;
+// the 8 groups x 4 waves are merged once at the end (shuffles, then LDS).  Four K rows and four V rows are in flight per lane.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct DecArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+  const uint8_t* key_valid;
+  int64_t ldk, ldv, sq, sk, sv, so;
+  int Lk, heads;
+  float scale_log2e;
+};
+
+__device__ __forceinline__ void unpack8(const uint4& t, float (&f)[8]) {
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+// (m, l, acc) <- merge with the state held by lane ^ mask (both lanes end up with the merged state)
+__device__ __forceinline__ void dec_merge_xor(float& m, float& l, float (&acc)[8], int mask) {
+  const float m2 = __shfl_xor(m, mask), l2 = __shfl_xor(l, mask);
+  const float mn = fmaxf(m, m2);
+  const float c1 = mn == -INFINITY ? 0.f : exp2f(m - mn), c2 = mn == -INFINITY ? 0.f : exp2f(m2 - mn);
+  l = l * c1 + l2 * c2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = acc[i] * c1 + __shfl_xor(acc[i], mask) * c2;
+  m = mn;
+}
+
+__global__ __launch_bounds__(256) void attn_decode64_kernel(const DecArgs a) {
+  __shared__ float sm[4][8][10];  // per wave: m, l, acc[8] of each of the 8 dim-slices (after the in-wave merge)
+  const int pair = blockIdx.x, n = pair / a.heads, h = pair - n * a.heads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 3, sub = lane & 7;
+  float qf[8];
+  {
+    const uint4 t = *reinterpret_cast<const uint4*>(a.q + n * a.sq + h * 64 + sub * 8);
+    unpack8(t, qf);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[i] *= a.scale_log2e;
+  }
+  const bf16_t* kb = a.k + n * a.sk + h * 64 + sub * 8;
+  const bf16_t* vb = a.v + n * a.sv + h * 64 + sub * 8;
+  const uint8_t* kv = a.key_valid ? a.key_valid + (int64_t)n * a.Lk : nullptr;
+  float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // wave w takes key blocks w, w + 4, ... of 32 keys (4 rows per 8-lane group)
+  for (int k0 = wave * 32; k0 < a.Lk; k0 += 128) {
+    uint4 kr[4], vr[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = k0 + u * 8 + grp;
+      ok[u] = key < a.Lk && (!kv || kv[key]);
+      const int kc = key < a.Lk ? key : a.Lk - 1;  // clamped: the row is read, its score is masked
+      kr[u] = *reinterpret_cast<const uint4*>(kb + (int64_t)kc * a.ldk);
+      vr[u] = *reinterpret_cast<const uint4*>(vb + (int64_t)kc * a.ldv);
+    }
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float kf[8];
+      unpack8(kr[u], kf);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d = fmaf(qf[i], kf[i], d);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      d += __shfl_xor(d, 4);
+      s[u] = ok[u] ? d : -INFINITY;
+    }
+    const float mn = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
+    if (mn != -INFINITY) {
+      const float c = exp2f(m - mn);  // m = -inf on the first live block: c = 0, acc and l are 0 anyway
+      l *= c;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] *= c;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float p = exp2f(s[u] - mn);  // -inf -> 0
+        float vf[8];
+        unpack8(vr[u], vf);
+        l += p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vf[i], acc[i]);
+      }
+      m = mn;
+    }
+  }
+  dec_merge_xor(m, l, acc, 8);
+  dec_merge_xor(m, l, acc, 16);
+  dec_merge_xor(m, l, acc, 32);
+  if (grp == 0) {
+    sm[wave][sub][0] = m;
+    sm[wave][sub][1] = l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[wave][sub][2 + i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int sb = threadIdx.x;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mt = fmaxf(mt, sm[w][sb][0]);
+    float lt = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (mt != -INFINITY) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float c = exp2f(sm[w][sb][0] - mt);
+        lt += sm[w][sb][1] * c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += sm[w][sb][2 + i] * c;
+      }
+    }
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;  // a row with no valid key gives exact zeros (as the fused forward)
+    uint4 w4;
+    w4.x = f32x2_to_bf16x2(o[0] * inv, o[1] * inv);
+    w4.y = f32x2_to_bf16x2(o[2] * inv, o[3] * inv);
+    w4.z = f32x2_to_bf16x2(o[4] * inv, o[5] * inv);
+    w4.w = f32x2_to_bf16x2(o[6] * inv, o[7] * inv);
+    *reinterpret_cast<uint4*>(a.o + n * a.so + h * 64 + sb * 8) = w4;
+  }
+}
+}  // namespace
+
+extern "C" int case_attention_decode_supported(int64_t head_dim) { return head_dim == 64; }
+
+extern "C" int case_attention_decode(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                                     void* out, case_stream_t stream) {
+  CASE_REQUIRE(d && q && k && v && out, "case_attention_decode: null argument");
+  CASE_REQUIRE(d->N > 0 && d->heads > 0 && d->Lk > 0, "case_attention_decode: empty problem");
+  CASE_REQUIRE(d->Lq == 1 && !d->causal && d->drop_p == 0.f, "case_attention_decode: one query per sequence, no causal mask, no dropout");
+  CASE_REQUIRE(case_attention_decode_supported(d->head_dim), "case_attention_decode: head_dim %lld not built (64)", (long long)d->head_dim);
+  CASE_REQUIRE(d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->sq % 8 == 0 && d->sk % 8 == 0 && d->sv % 8 == 0 && d->so % 8 == 0 &&
+                   (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "case_attention_decode: operands must be 16-byte aligned with strides that are multiples of 8 elements");
+  CASE_REQUIRE(d->N * d->heads < (1ll << 31), "case_attention_decode: grid too large");
+  DecArgs a;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)out;
+  a.key_valid = key_valid;
+  a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv; a.so = d->so;
+  a.Lk = (int)d->Lk; a.heads = (int)d->heads;
+  a.scale_log2e = d->scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_decode64_kernel, dim3((unsigned)(d->N * d->heads)), dim3(256), 0, (hipStream_t)stream, a);
+  return case_check_launch("case_attention_decode");
+}

@@ -408,13 +408,17 @@ extern "C" int case_additive_scores_fwd(const float* wq, const void* uh, const f
   if (T <= 2 && H % ev == 0 && H <= 2 * 64 * ev && (uintptr_t)uh % 16 == 0) {  // decode steps (T = 1)
     const dim3 g((unsigned)((S + 15) / 16 < 64 ? (S + 15) / 16 : 64), (unsigned)B);
     const bool one = H <= 64 * ev;
+    // T = 1 (every greedy step) gets its own instantiation: the kernel is bound by the tanh issue rate, and the two-row form
+    // evaluates the absent second row as well
+#define ROWWISE(TY, FAST, TT, NCH) hipLaunchKernelGGL((additive_fwd_rowwise_kernel<TY, FAST, TT, NCH>), g, dim3(256), 0, st, wq, (const TY*)uh, v, s, T, S, H)
     if (dtype == CASE_F32) {
-      if (one) hipLaunchKernelGGL((additive_fwd_rowwise_kernel<float, false, 2, 1>), g, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
-      else hipLaunchKernelGGL((additive_fwd_rowwise_kernel<float, false, 2, 2>), g, dim3(256), 0, st, wq, (const float*)uh, v, s, T, S, H);
+      if (T == 1) { if (one) ROWWISE(float, false, 1, 1); else ROWWISE(float, false, 1, 2); }
+      else { if (one) ROWWISE(float, false, 2, 1); else ROWWISE(float, false, 2, 2); }
     } else {
-      if (one) hipLaunchKernelGGL((additive_fwd_rowwise_kernel<bf16_t, true, 2, 1>), g, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
-      else hipLaunchKernelGGL((additive_fwd_rowwise_kernel<bf16_t, true, 2, 2>), g, dim3(256), 0, st, wq, (const bf16_t*)uh, v, s, T, S, H);
+      if (T == 1) { if (one) ROWWISE(bf16_t, true, 1, 1); else ROWWISE(bf16_t, true, 1, 2); }
+      else { if (one) ROWWISE(bf16_t, true, 2, 1); else ROWWISE(bf16_t, true, 2, 2); }
     }
+#undef ROWWISE
     return case_check_launch("case_additive_scores_fwd");
   }
   const dim3 grid((unsigned)((S + AJ - 1) / AJ), (unsigned)B);

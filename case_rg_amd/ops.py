@@ -116,6 +116,8 @@ def cast(x, dtype):
 GEMM_TILE = 0
 # Measurement aid (bench.py): when a list, every launch appends the tile edge case_gemm_tile_for() reports for it.
 TILE_TRACE = None
+# Fewest (sequence, head) pairs for which the one-workgroup-per-pair decode attention kernel is used (below: split-KV forward)
+DECODE_MIN_PAIRS = 192
 # Bias gradients of the weight-gradient GEMMs inside the same launch (False: always the separate column-sum pass; A/B measurements)
 FUSE_BIAS_GRAD = True
 
@@ -598,6 +600,15 @@ class AttentionFn(Function):
         drop = (p_drop,) + config.next_rng(N * heads * Lq * Lk) if p_drop > 0.0 else None
         O = torch.empty(N, Lq, E, dtype=dt, device=dev)
         fused = _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, any(ctx.needs_input_grad[:3]))
+        if (fused and Lq == 1 and not causal and drop is None and not any(ctx.needs_input_grad[:3]) and N * heads >= DECODE_MIN_PAIRS
+                and A.lib.case_attention_decode_supported(d)):
+            # greedy decode step: one query per sequence against the cached keys / values -- the streaming kernel (no LSE: nothing
+            # to differentiate); few (sequence, head) pairs with a long memory keep the split-KV forward below
+            ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, None)
+            A.call("case_attention_decode", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O),
+                   _stream())
+            ctx.meta = None
+            return O
         if fused:
             lse = torch.empty(N, heads, Lq, dtype=torch.float32, device=dev)
             ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)

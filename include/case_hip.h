@@ -190,6 +190,12 @@ int case_attention_splitkv_workspace(const CaseAttnDesc* d, int32_t ksplit, int6
 int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                                void* out, float* lse, void* workspace, int64_t workspace_bytes, int32_t ksplit,
                                case_stream_t stream);
+/* Decode step (greedy inference, CaSE/Model.py:94-123 with cached projections): ONE query per sequence (d->Lq == 1) against
+ * Lk cached keys / values, no causal mask, no dropout, no LSE (nothing to differentiate).  HBM-bound streaming kernel, one
+ * workgroup per (sequence, head); out [N, 1, heads*head_dim].  Rows without a valid key give exact zeros. */
+int case_attention_decode_supported(int64_t head_dim);
+int case_attention_decode(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                          void* out, case_stream_t stream);
 int case_attention_bwd_supported(int64_t head_dim);
 int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                        const void* out, const float* lse, const void* dout, float* delta, void* dq, void* dk, void* dv,

@@ -135,6 +135,37 @@ def test_attention(dt, N, h, Lq, Lk, d, causal):
         _close(kv.grad, rkv.grad, 2 * _tol(dt), "attn dkv")
 
 
+@pytest.mark.parametrize("N,h,Lk", [(32, 8, 3840), (40, 8, 37), (24, 8, 64), (300, 1, 129)])
+def test_attention_decode_step(N, h, Lk):
+    """One query per sequence against cached keys / values (the greedy step's cross- and self-attention): the streaming kernel
+    against torch and against the general fused forward; ragged validity, one sequence without any valid key (exact zeros)."""
+    ops = _ops()
+    d, E, dt = 64, h * 64, torch.bfloat16
+    q = _rand(N, 1, E, dt=dt, seed=1, scale=0.5)
+    kv = _rand(N, Lk, 2 * E, dt=dt, seed=2, scale=0.5)
+    g = torch.Generator().manual_seed(3)
+    valid = (torch.rand(N, Lk, generator=g) > 0.2).to(DEV)
+    valid[0] = True
+    valid[1] = False
+    valid[2, Lk // 3:] = False
+    assert N * h >= ops.DECODE_MIN_PAIRS
+    with torch.no_grad():
+        o = ops.attention(q, kv, kv, 0, 0, E, h, d, key_valid=valid)
+        keep, ops.DECODE_MIN_PAIRS = ops.DECODE_MIN_PAIRS, 1 << 30
+        try:
+            general = ops.attention(q, kv, kv, 0, 0, E, h, d, key_valid=valid)
+        finally:
+            ops.DECODE_MIN_PAIRS = keep
+    k, v = kv.float().split(E, dim=-1)
+    qh, kh, vh = [t.reshape(N, -1, h, d).transpose(1, 2) for t in (q.float(), k, v)]
+    s = (qh @ kh.transpose(-1, -2) / math.sqrt(d)).masked_fill(~valid[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    ref = (p @ vh).transpose(1, 2).reshape(N, 1, E)
+    _close(o, ref, _tol(dt), "decode attention vs torch")
+    _close(o, general.float(), 1e-2, "decode attention vs the general fused forward")
+    assert torch.count_nonzero(o[1]) == 0, "no valid key: exact zeros"
+
+
 def test_softmax_masks_and_empty_rows():
     ops = _ops()
     x = _rand(2, 6, 9, seed=1).requires_grad_()
