@@ -49,6 +49,7 @@ struct Args {
 #undef GEMM_NTHREADS
 
 #include "gemm8w.inc"
+#include "gemm_small.inc"
 
 namespace {
 constexpr int BM = 128, BN = 128, ROWB = 128;
@@ -74,7 +75,7 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
   CASE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "case_gemm: empty problem M=%lld N=%lld K=%lld", (long long)d->M,
                (long long)d->N, (long long)d->K);
   CASE_REQUIRE(d->batch1 > 0 && d->batch2 > 0, "case_gemm: batch must be positive");
-  CASE_REQUIRE(d->tile == 0 || d->tile == 128 || d->tile == 256, "case_gemm: tile must be 0, 128 or 256");
+  CASE_REQUIRE(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256, "case_gemm: tile must be 0, 64, 128 or 256");
   const int epi = d->epilogue;
   CASE_REQUIRE(!(epi & CASE_EPI_BIAS_COL) || bias_col, "case_gemm: BIAS_COL without bias_col");
   CASE_REQUIRE(!(epi & CASE_EPI_BIAS_ROW) || bias_row, "case_gemm: BIAS_ROW without bias_row");
@@ -134,7 +135,16 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
     // k-major operands advance by 64 leading-dimension rows per K tile through a 32-bit DMA offset
     const bool span_ok = (!d->a_kmajor || (d->K / a.split_k + 64) * d->lda < (1ll << 30)) &&
                          (!d->b_kmajor || (d->K / a.split_k + 64) * d->ldb < (1ll << 30));
-    if (span_ok && (d->tile == 256 || gemm_t8w::prefer(nwg, t256, device_cus()))) *tile = 256;
+    if (span_ok && d->tile != 64 && (d->tile == 256 || gemm_t8w::prefer(nwg, t256, device_cus()))) *tile = 256;
+  }
+  // small problems (the 128x128 tiling cannot fill the chip once): 64x64 tiles with the whole K panel resident in LDS
+  if (*tile == 128 && d->tile != 128 && d->tile != 256 && d->in_dtype == CASE_BF16 && d->batch1 * d->batch2 == 1 && d->M % 64 == 0 &&
+      d->N % 64 == 0 && d->K % 64 == 0 && a.k_tiles_per_split <= gemm_sm::MAXKT && a.vec_a && a.vec_b && d->lda < (1 << 22) &&
+      d->ldb < (1 << 22) && (!(epi & CASE_EPI_ATOMIC) || d->out_dtype == CASE_F32)) {
+    const int64_t t64 = (d->M / 64) * (d->N / 64) * a.split_k;
+    const bool span_ok = (!d->a_kmajor || (int64_t)a.k_tiles_per_split * 64 * d->lda < (1ll << 30)) &&
+                         (!d->b_kmajor || (int64_t)a.k_tiles_per_split * 64 * d->ldb < (1ll << 30));
+    if (span_ok && (d->tile == 64 || (nwg < device_cus() && t64 <= 2 * device_cus()))) *tile = 64;
   }
   return 0;
 }
@@ -176,6 +186,10 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
     if (d->out_dtype == CASE_BF16) return gemm_t8w::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
     if (epi & CASE_EPI_ATOMIC) return gemm_t8w::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
     return gemm_t8w::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+  }
+  if (tile == 64) {
+    if (d->out_dtype == CASE_BF16) return gemm_sm::launch<bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
+    return gemm_sm::launch<float>(a, epi, d->a_kmajor, d->b_kmajor, s);
   }
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return gemm_w4::launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return gemm_w4::launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);

@@ -185,6 +185,15 @@ def _split_for(out_rows, out_cols, k_len, elem_bytes):
                 best, best_score = split, score
         return best
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    if elem_bytes == 2 and out_rows % 64 == 0 and out_cols % 64 == 0 and k_len % 64 == 0 and tiles < 128:
+        # small output (the decoder- / query-side weight gradients): the 64x64 tiling holds <= 10 K tiles per workgroup in LDS and
+        # wants about one round of workgroups, <= 512 in all (csrc/gemm_small.inc, case_gemm's choice)
+        t64 = (out_rows // 64) * (out_cols // 64)
+        need = (k_tiles + 9) // 10
+        want = max(need, (256 + t64 - 1) // t64)
+        split = min(want, k_tiles, max(need, 512 // t64))
+        if (k_tiles + split - 1) // split <= 10 and t64 * split <= 512:
+            return max(1, split)
     min_k_tiles = 8 if tiles >= 128 else 2
     best, best_eff = 1, 0.0
     for split in range(1, 65):

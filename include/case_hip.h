@@ -78,8 +78,8 @@ typedef struct {
   int32_t out_dtype; /* dtype of C */
   int32_t epilogue;  /* CASE_EPI_* mask */
   int32_t split_k;   /* >= 1 */
-  int32_t tile;      /* 0 = pick the tiling per call (cost model); 128 = the 128x128 tiling; 256 = the 256x256 persistent tiling
-                        whenever the call is eligible for it (otherwise 128x128) */
+  int32_t tile;      /* 0 = pick the tiling per call (cost model); 128 = the 128x128 tiling; 256 = the 256x256 persistent tiling,
+                        64 = the small-problem tiling (whole K panel in LDS) whenever the call is eligible (otherwise 128x128) */
   float alpha;
   float drop_p;
   uint64_t seed, offset;
@@ -88,9 +88,10 @@ typedef struct {
 int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
               const float* bias_row, const void* aux, void* aux_out, case_stream_t stream);
 
-/* case_gemm owns two tilings: 128x128 (every shape / dtype / batch) and 256x256 (bf16, M % 256 == N % 256 == 0,
- * K % 64 == 0, unbatched, 16-byte aligned; eight waves, operands by LDS-DMA, persistent: csrc/gemm8w.inc).  CaseGemmDesc.tile selects per call; results
- * of the two tilings agree to f32 summation order.  case_gemm_tile_for() returns the tile edge (128 or 256) case_gemm would
+/* case_gemm owns three tilings: 128x128 (every shape / dtype / batch), 256x256 (bf16, M % 256 == N % 256 == 0,
+ * K % 64 == 0, unbatched, 16-byte aligned; eight waves, operands by LDS-DMA, persistent: csrc/gemm8w.inc) and 64x64 for small
+ * problems (bf16, multiples of 64, <= 10 K tiles per split, the 128x128 grid smaller than the chip: csrc/gemm_small.inc).  CaseGemmDesc.tile selects per call; results
+ * of the tilings agree to f32 summation order.  case_gemm_tile_for() returns the tile edge (64, 128 or 256) case_gemm would
  * launch for exactly these arguments (or a negative CASE_E_* code): a pure function of its arguments, no launch, no state --
  * bench.py uses it to attribute each launch to the kernel name rocprofv3 reports. */
 /* Weight-gradient GEMM that also produces the bias gradient (replaces a separate pass over dY, case_colsum; reference:

@@ -197,6 +197,8 @@ def test_split_k_heuristic_fills_whole_rounds():
         wgs = (rows // 256) * (cols // 256) * split
         assert wgs / (-(-wgs // 256) * 256.0) >= 0.92, (rows, cols, split)
         assert (k // 64) // split >= 8
-    assert ops._split_for(512, 512, 1280, 2) == 10          # 16 tiles of 128: two K tiles per split keep 160 workgroups busy
+    assert ops._split_for(512, 512, 1280, 2) == 4           # small output: 64 tiles of 64x64 x 4 splits = 256 workgroups, 5 K tiles each in LDS
+    assert ops._split_for(512, 512, 2048, 2) == 4 and ops._split_for(1536, 512, 1280, 2) == 2
+    assert ops._split_for(320, 512, 1280, 2) >= 5           # not a multiple of 64: 128x128 tiling, few K tiles per split
     assert ops._split_for(30522, 512, 1280, 2) <= 2         # 956 tiles already fill the chip
     assert ops._split_for(64, 64, 64, 4) == 1               # nothing to split

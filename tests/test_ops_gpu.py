@@ -616,6 +616,79 @@ def test_gemm_large_tile_epilogues_and_persistence():
     _close(large, small.float(), 1e-2, "persistent: tilings agree")
 
 
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_small_tile_layouts_and_epilogues(layout):
+    """64x64 tiling (whole K panel in LDS) against the 128x128 tiling and torch: 1..10 K tiles, every operand layout, the
+    epilogue words of the decoder-side projections, split-K atomics."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    dt = torch.bfloat16
+
+    def both(fn):
+        with _Tile(128):
+            small = fn()
+        with _Tile(64):
+            tiny = fn()
+        torch.cuda.synchronize()
+        return small, tiny
+
+    for (M, N, K) in ((64, 64, 64), (256, 512, 512), (1280, 512, 512), (128, 192, 640), (320, 64, 192)):
+        if layout == "nt":
+            a, b = _rand(M, K, dt=dt, seed=1), _rand(N, K, dt=dt, seed=2, scale=K ** -0.5)
+            ref = a.float() @ b.float().t()
+            fn = lambda: ops.gemm(a, b, torch.full((M, N), float("nan"), device="cuda", dtype=dt), M, N, K, K, K, N)
+        elif layout == "nn":
+            a, b = _rand(M, K, dt=dt, seed=1), _rand(K, N, dt=dt, seed=2, scale=K ** -0.5)
+            ref = a.float() @ b.float()
+            fn = lambda: ops.gemm(a, b, torch.full((M, N), float("nan"), device="cuda", dtype=dt), M, N, K, K, N, N, b_kmajor=True)
+        else:
+            a, b = _rand(K, M, dt=dt, seed=1), _rand(K, N, dt=dt, seed=2, scale=K ** -0.5)
+            ref = a.float().t() @ b.float()
+            fn = lambda: ops.gemm(a, b, torch.full((M, N), float("nan"), device="cuda", dtype=dt), M, N, K, M, N, N, a_kmajor=True,
+                                  b_kmajor=True)
+        small, tiny = both(fn)
+        _close(tiny, ref, 2e-2, "small tile %s M=%d N=%d K=%d" % (layout, M, N, K))
+        _close(tiny, small.float(), 1e-2, "tilings agree %s M=%d N=%d K=%d" % (layout, M, N, K))
+    if layout != "nt":
+        return
+    M, N, K = 256, 512, 512
+    x, w = _rand(M, K, dt=dt, seed=1), _rand(N, K, dt=dt, seed=2, scale=K ** -0.5)
+    bias, res = _rand(N, seed=3), _rand(M, N, dt=dt, seed=4)
+
+    def gelu():
+        y, pre = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+        ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_GELU, bias_col=bias, aux_out=pre, ld_aux=N)
+        return torch.stack([y.float(), pre.float()])
+    small, tiny = both(gelu)
+    _close(tiny[0], F.gelu(x.float() @ w.float().t() + bias), 2e-2, "small tile gelu")
+    _close(tiny, small, 1e-2, "gelu epilogue: tilings agree")
+
+    def drop_res():
+        y = torch.empty(M, N, device="cuda", dtype=dt)
+        ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_RESIDUAL, bias_col=bias, aux=res, ld_aux=N,
+                 drop=(0.25, 1234, 77))
+        return y.float()
+    small, tiny = both(drop_res)
+    _close(tiny, small, 1e-2, "dropout + residual: same keep mask in both tilings")
+
+    def f32_out():
+        return ops.gemm(x, w, torch.empty(M, N, device="cuda", dtype=torch.float32), M, N, K, K, K, N, alpha=0.5)
+    small, tiny = both(f32_out)
+    _close(tiny, 0.5 * (x.float() @ w.float().t()), 1e-3, "small tile f32 out")
+    Kl = 64 * 11  # split-K weight gradient with uneven splits (4, 4, 3 K tiles)
+    g, xx = _rand(Kl, M, dt=dt, seed=5), _rand(Kl, N, dt=dt, seed=6, scale=Kl ** -0.5)
+
+    def dw():
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+        return ops.gemm(g, xx, out, M, N, Kl, M, N, N, a_kmajor=True, b_kmajor=True, split_k=3, epilogue=A.EPI_ATOMIC)
+    small, tiny = both(dw)
+    _close(tiny, g.float().t() @ xx.float(), 2e-3, "small tile split-K")
+    with _Tile(64):  # more than 10 K tiles per split: not eligible, the call falls back to 128x128 (and stays correct)
+        big = ops.gemm(_rand(64, 1024, dt=dt, seed=7), _rand(64, 1024, dt=dt, seed=8), torch.empty(64, 64, device="cuda", dtype=dt),
+                       64, 64, 1024, 1024, 1024, 64)
+    _close(big, _rand(64, 1024, dt=dt, seed=7).float() @ _rand(64, 1024, dt=dt, seed=8).float().t(), 2e-2, "fallback")
+
+
 def test_weight_gradient_gemm_also_sums_the_bias_gradient():
     """case_gemm_dw_bias: dW = dY^T X with the bias gradient (column sums of dY) taken from the k-major A fragments of the same
     launch (256x256 tiling), and the fallback (separate column-sum pass) for calls the large tiling does not take."""
