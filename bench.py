@@ -152,7 +152,7 @@ def roofline_step(a, trainer, opt, sched, batch):
         out = raw(A_, B_, C_, M, N, K, *args, **kw)
         e1.record()
         tile = ops.TILE_TRACE[-1]  # which tiling case_gemm picks for this launch (rocprofv3 names the two kernels apart)
-        key = "%s<%s,%s,%s,%s>" % ("gemm8w_kernel" if tile == 256 else "gemm_kernel", "bf16" if A_.dtype == torch.bfloat16 else "f32",
+        key = "%s<%s,%s,%s,%s>" % ({256: "gemm8w_kernel", 64: "gemm_small_kernel"}.get(tile, "gemm_kernel"), "bf16" if A_.dtype == torch.bfloat16 else "f32",
                                    "bf16" if C_.dtype == torch.bfloat16 else "f32",
                                    "Ak" if kw.get("a_kmajor") else "A", "Bk" if kw.get("b_kmajor") else "B")
         nb = kw.get("batch1", 1) * kw.get("batch2", 1)

@@ -22,6 +22,10 @@ def family(name):
     if m:
         return "gemm8w_kernel<bf16,%s,%s,%s>" % ("bf16" if m.group(1) == "unsigned short" else "f32",
                                                     "Ak" if m.group(2) == "true" else "A", "Bk" if m.group(3) == "true" else "B")
+    m = re.search(r"gemm_small_kernel<(unsigned short|float), (true|false), (true|false)>", name)
+    if m:
+        return "gemm_small_kernel<bf16,%s,%s,%s>" % ("bf16" if m.group(1) == "unsigned short" else "f32",
+                                                       "Ak" if m.group(2) == "true" else "A", "Bk" if m.group(3) == "true" else "B")
     m = re.search(r"gemm_kernel<(unsigned short|float), (unsigned short|float), (true|false), (true|false), (true|false)>", name)
     if m:
         t = {"unsigned short": "bf16", "float": "f32"}
