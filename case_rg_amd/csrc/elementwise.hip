@@ -249,6 +249,39 @@ __global__ void embed_pos_fwd_kernel(const int64_t* __restrict__ ids, const floa
   }
 }
 
+// vector form (H % 8 == 0, 16-byte aligned table / pe / out): a thread owns 8 consecutive features of one row -- one id load,
+// two 16-byte table loads, two of the position table, one 16-byte (bf16) or two (f32) stores; 32-bit index arithmetic.  The
+// scalar kernel above spends a 64-bit divide and modulo per element and ran at 2.5 TB/s.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pos_fwd_vec_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                                const float* __restrict__ pe, T* __restrict__ out, unsigned chunks,
+                                                                unsigned seq_len, unsigned H8, int64_t vocab, float scale, float drop_p,
+                                                                uint64_t seed, uint64_t offset) {
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (unsigned ci = blockIdx.x * 256u + threadIdx.x; ci < chunks; ci += gridDim.x * 256u) {
+    const unsigned r = ci / H8, c = (ci - r * H8) * 8u;
+    int64_t id = ids[r];
+    if (id < 0 || id >= vocab) id = 0;
+    const float* tp = table + id * (int64_t)(H8 * 8u) + c;
+    const float* pp = pe + (int64_t)(r % seq_len) * (H8 * 8u) + c;
+    const float4 t0 = *reinterpret_cast<const float4*>(tp), t1 = *reinterpret_cast<const float4*>(tp + 4);
+    const float4 p0 = *reinterpret_cast<const float4*>(pp), p1 = *reinterpret_cast<const float4*>(pp + 4);
+    float v[8] = {fmaf(t0.x, scale, p0.x), fmaf(t0.y, scale, p0.y), fmaf(t0.z, scale, p0.z), fmaf(t0.w, scale, p0.w),
+                  fmaf(t1.x, scale, p1.x), fmaf(t1.y, scale, p1.y), fmaf(t1.z, scale, p1.z), fmaf(t1.w, scale, p1.w)};
+    if (drop_p > 0.f) dropout8(v, seed, offset + (uint64_t)r * (H8 * 8u) + c, drop_p, ks);
+    T* op = out + (int64_t)r * (H8 * 8u) + c;
+    if constexpr (sizeof(T) == 2) {
+      uint4 w;
+      w.x = f32x2_to_bf16x2(v[0], v[1]); w.y = f32x2_to_bf16x2(v[2], v[3]);
+      w.z = f32x2_to_bf16x2(v[4], v[5]); w.w = f32x2_to_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(op) = w;
+    } else {
+      *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
 template <typename T>
 __global__ void embed_pos_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d_out,
                                      float* __restrict__ d_table, int64_t rows, int64_t H, int64_t vocab, float scale,
@@ -559,6 +592,19 @@ extern "C" int case_embed_pos_fwd(const int64_t* ids, const float* table, const 
                                   int64_t seq_len, int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed,
                                   uint64_t offset, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(ids && table && pe && out && rows > 0 && seq_len > 0 && H > 0 && vocab > 0, "case_embed_pos_fwd: bad argument");
+  if ((dtype == CASE_BF16 || dtype == CASE_F32) && H % 8 == 0 && al16(table) && al16(pe) && al16(out) && rows * (H / 8) < (1ll << 31) &&
+      seq_len < (1ll << 31)) {
+    const unsigned chunks = (unsigned)(rows * (H / 8));
+    const dim3 grid((unsigned)grid_for(chunks, 256, 1, 256 * 16));
+    hipStream_t s_ = (hipStream_t)stream;
+    if (dtype == CASE_F32)
+      hipLaunchKernelGGL(embed_pos_fwd_vec_kernel<float>, grid, dim3(256), 0, s_, ids, table, pe, (float*)out, chunks, (unsigned)seq_len,
+                         (unsigned)(H / 8), vocab, scale, drop_p, seed, offset);
+    else
+      hipLaunchKernelGGL(embed_pos_fwd_vec_kernel<bf16_t>, grid, dim3(256), 0, s_, ids, table, pe, (bf16_t*)out, chunks, (unsigned)seq_len,
+                         (unsigned)(H / 8), vocab, scale, drop_p, seed, offset);
+    return case_check_launch("case_embed_pos_fwd");
+  }
   EW_DISPATCH("case_embed_pos_fwd", rows * H, embed_pos_fwd_kernel, ids, table, pe, (T*)out, rows, seq_len, H, vocab, scale,
               drop_p, seed, offset);
 }
