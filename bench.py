@@ -100,6 +100,8 @@ def build(a, device):
 
     case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     case_rg_amd.set_dropout(not a.no_dropout)
+    if os.environ.get("CASE_ATTENTION_MODE"):  # A/B switch: "fused" / "unfused" instead of the per-head-dim policy
+        case_rg_amd.ops.ATTENTION_MODE = os.environ["CASE_ATTENTION_MODE"]
     if os.environ.get("CASE_NO_FUSED_BIAS_GRAD"):  # A/B switch: bias gradients by the separate column-sum pass
         case_rg_amd.ops.FUSE_BIAS_GRAD = False
     init_seed(123456)  # the reference's seed (CaSE/Run.py:92)
