@@ -689,6 +689,63 @@ def test_gemm_small_tile_layouts_and_epilogues(layout):
     _close(big, _rand(64, 1024, dt=dt, seed=7).float() @ _rand(64, 1024, dt=dt, seed=8).float().t(), 2e-2, "fallback")
 
 
+@pytest.mark.parametrize("tile", [64, 256])
+def test_gemm_dma_tilings_with_padded_leading_dimensions(tile):
+    """The LDS-DMA tilings address operands through (row * ld) byte offsets: operands and C that are column blocks of wider
+    buffers (ld > extent), NT and the k-major layouts, aux with its own ld."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    dt = torch.bfloat16
+    M, N, K = (512, 256, 320) if tile == 256 else (128, 192, 320)
+    big_a, big_b = _rand(M, K + 64, dt=dt, seed=1), _rand(N, K + 128, dt=dt, seed=2, scale=K ** -0.5)
+    a, b = big_a[:, 64:], big_b[:, 128:]                      # row-major views: lda = K + 64, ldb = K + 128
+    big_c = torch.full((M, N + 64), float("nan"), device="cuda", dtype=dt)
+    big_r = _rand(M, N + 32, dt=dt, seed=3)
+    bias = _rand(N, seed=4)
+    with _Tile(tile):
+        ops.gemm(big_a, big_b, big_c, M, N, K, K + 64, K + 128, N + 64, a_off=64, b_off=128, c_off=64, epilogue=A.EPI_BIAS_COL | A.EPI_RESIDUAL,
+                 bias_col=bias, aux=big_r, ld_aux=N + 32)
+    torch.cuda.synchronize()
+    ref = a.float() @ b.float().t() + bias + big_r[:, :N].float()
+    _close(big_c[:, 64:], ref, 2e-2, "padded NT tile %d" % tile)
+    assert torch.isnan(big_c[:, :64].float()).all(), "columns outside the C block untouched"
+    # k-major operands inside wider buffers (the weight-gradient layout)
+    ga, gb = _rand(K, M + 64, dt=dt, seed=5), _rand(K, N + 64, dt=dt, seed=6, scale=K ** -0.5)
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    with _Tile(tile):
+        ops.gemm(ga, gb, out, M, N, K, M + 64, N + 64, N, a_off=64, b_off=0, a_kmajor=True, b_kmajor=True, split_k=1, epilogue=A.EPI_ATOMIC)
+    torch.cuda.synchronize()
+    _close(out, ga[:, 64:].float().t() @ gb[:, :N].float(), 2e-3, "padded TN tile %d" % tile)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_gemm_large_tile_is_bit_reproducible(layout):
+    """Race screen of the LDS-DMA pipeline (counted waits, barriers, stage re-use, strips under the next tile's prologue): the
+    non-atomic kernels have a fixed summation order, so repeated launches must agree bit for bit -- on an output prefilled with
+    NaN, with more tiles than CUs (persistent loop) and an odd number of K tiles."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    dt = torch.bfloat16
+    M, N, K = 5120, 4352, 448  # 20 x 17 = 340 tiles on 256 CUs, 7 K tiles
+    a = _rand(M, K, dt=dt, seed=1)
+    b = _rand(N, K, dt=dt, seed=2, scale=K ** -0.5) if layout == "nt" else _rand(K, N, dt=dt, seed=2, scale=K ** -0.5)
+    bias, res = _rand(N, seed=3), _rand(M, N, dt=dt, seed=4)
+    first = None
+    with _Tile(256):
+        for rep in range(12):
+            c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+            if layout == "nt":
+                ops.gemm(a, b, c, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_RESIDUAL, bias_col=bias, aux=res, ld_aux=N)
+            else:
+                ops.gemm(a, b, c, M, N, K, K, N, N, b_kmajor=True, epilogue=A.EPI_BIAS_COL | A.EPI_RESIDUAL, bias_col=bias, aux=res, ld_aux=N)
+            if first is None:
+                first = c
+                ref = (a.float() @ (b.float().t() if layout == "nt" else b.float())) + bias + res.float()
+                _close(c, ref, 2e-2, "reference %s" % layout)
+            else:
+                assert torch.equal(c, first), "launch %d differs from launch 0 (%s)" % (rep, layout)
+
+
 def test_weight_gradient_gemm_also_sums_the_bias_gradient():
     """case_gemm_dw_bias: dW = dY^T X with the bias gradient (column sums of dY) taken from the k-major A fragments of the same
     launch (256x256 tiling), and the fallback (separate column-sum pass) for calls the large tiling does not take."""
