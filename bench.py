@@ -12,16 +12,25 @@ encoder layers, 10 passages x 384 tokens, 64-token query, 40-token answer, batch
 dropout ON (counter RNG), full-length sequences (padded-dense FLOPs == useful FLOPs).  Weak scaling:
 every rank runs the same per-GPU batch; value = N * B * (Lq + P*Lp) * K / max-over-ranks time.
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts the N ranks ITSELF: before anything touches
+the GPU the parent spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays rank 0's
+JSON line and exits with the child's code (it never initialises the GPU).  The line carries `world_size` as
+`dist.get_world_size()` reports it and every rank's own step time.
+
 Extra objects in the JSON line:
   roofline      dominant kernel family (the bf16 MFMA GEMM instantiation with the largest total time): algorithmic
                 FLOPs per launch / average launch duration, both measured live with HIP events on the launch stream
                 over one instrumented step after the timed region; peak = 2516.6 TFLOP/s dense bf16.
   cpu_baseline  the CPU oracle (a port of the reference, oracle/) timed on this host's cores on a bounded sample
-                (one training step at batch 1 of the same shapes), rank 0, N = 1 only.
+                (training steps at batch 1 of the same shapes, at the fastest of several thread counts), rank 0, N = 1 only.
+  north_star    (default mode, N = 1) the encoder-forward point of BASELINE.json's target measured in the same process after
+                the timed region: TransformerSeqEncoder forward at 64 x 10 x 384 tokens, 6 layers, ms / TFLOP/s / fraction of peak.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,6 +59,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the encoder-forward point appended to the default line")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the BASELINE workload keeps dropout on")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
     ap.add_argument("--mode", default="train", choices=["train", "decode", "encoder", "cfg5"],
@@ -229,27 +239,29 @@ def roofline_cross_attention(a, device):
             "launches_per_step": "8 forward (2 stacks x 4 layers; the query-memory stack has S = %d)" % a.query_len}
 
 
+def _thread_candidates(cores):
+    return sorted({c for c in (8, 16, 32, cores) if 0 < c <= cores})
+
+
 def cpu_baseline(a):
-    """The CPU oracle (fp32 port of the reference, oracle/) on this host: training steps (fwd + bwd + clip + Adam) at batch 1
-    on a bounded sample of the same shapes -- min(4, P) of the P passages per item (tokens/s is independent of P and B to
-    first order) -- one warm-up step, then the median of three with every core and one step with 8
-    threads (the survey container's count).  The oracle forms the Interaction scores from two small matrix products instead of
-    the reference's [P, Lp, Lq, 3H] tensor, so it is FASTER than the reference itself would be on this host."""
+    """The CPU oracle (fp32 port of the reference, oracle/) on this host: training steps (fwd + bwd + clip + Adam) at batch 1 of
+    the same shapes, ALL P passages.  The thread count matters more than the core count (128 threads ran 4.5x SLOWER than 8 in
+    round 2: oversubscribed intra-op pools), so the leg first probes one step at 8 / 16 / 32 / all threads on a 4-passage sample,
+    then reports as ``value`` the median of three full-size steps at the FASTEST setting (``cores`` = that thread count); every
+    probe is listed in ``by_threads``.  The oracle forms the Interaction scores from two small matrix products instead of the
+    reference's [P, Lp, Lq, 3H] tensor, so it is FASTER than the reference itself would be on this host."""
     import statistics
     import oracle
     from case_rg_amd.utils import fill_params, make_vocab, synth_batch
     v2i, i2v = make_vocab(a.vocab)
-    P = min(4, a.passages)
     if a.model == "case":
         m = oracle.CaSE(4, a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
     else:
         m = oracle.Masque(a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
     fill_params(m, 1).train()
-    b = synth_batch(1, P, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
     opt = torch.optim.Adam(m.parameters(), lr=2.5e-4)
-    tokens = a.query_len + P * a.passage_len
 
-    def step():
+    def step(b):
         t0 = time.time()
         losses = m(dict(b), method="train")
         sum(l.mean() for l in losses).backward()
@@ -258,19 +270,64 @@ def cpu_baseline(a):
         opt.zero_grad()
         return time.time() - t0
 
-    cores = torch.get_num_threads()
-    step()  # warm-up (allocator, thread pool, first-call overheads)
-    times = [step() for _ in range(3)]
+    host = torch.get_num_threads()
+    Ps = min(4, a.passages)
+    probe = synth_batch(1, Ps, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
+    full = synth_batch(1, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
+    tok_probe, tok_full = a.query_len + Ps * a.passage_len, a.query_len + a.passages * a.passage_len
+    by_threads = {}
+    torch.set_num_threads(min(8, host))
+    step(probe)  # warm-up (allocator, thread pool, first-call overheads)
+    for n in _thread_candidates(host):
+        torch.set_num_threads(n)
+        step(probe)
+        by_threads[str(n)] = round(tok_probe / step(probe), 1)
+    best = int(max(by_threads, key=lambda k: by_threads[k]))
+    torch.set_num_threads(best)
+    step(full)
+    times = [step(full) for _ in range(3)]
     med = statistics.median(times)
-    torch.set_num_threads(min(8, cores))
-    step()
-    t8 = step()
-    torch.set_num_threads(cores)
-    return {"value": round(tokens / med, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "value_8_threads": round(tokens / t8, 1),
-            "sample": "fp32 CPU oracle (decomposed Interaction: faster than the reference's own formulation), batch 1 x %d of %d "
-                      "passages x %d tokens, fwd+bwd+clip+Adam; 1 warm-up + median of 3 steps on %d threads (%.1f s each), 1 step on 8 "
-                      "threads (%.1f s)" % (P, a.passages, a.passage_len, cores, med, t8)}
+    torch.set_num_threads(host)
+    return {"value": round(tok_full / med, 1), "unit": "tokens/s", "cores": best, "host_cores": host, "kind": "port",
+            "by_threads": by_threads,
+            "sample": "fp32 CPU oracle (decomposed Interaction: faster than the reference's own formulation), batch 1 x %d passages x %d "
+                      "tokens, fwd+bwd+clip+Adam; thread count probed on a %d-passage step (tokens/s by threads in by_threads), then 1 "
+                      "warm-up + median of 3 full steps at the fastest setting, %d threads (%.1f s each)" % (
+                          a.passages, a.passage_len, Ps, best, med)}
+
+
+def cpu_baseline_decode(a):
+    """Decode leg of the CPU baseline: the oracle's greedy ``do_test`` (the reference's own O(T^2) loop, CaSE/Model.py:91-123: the
+    whole prefix is re-decoded every step) for ONE query with all P passages and the full T-token answer, on the thread count that
+    is fastest for it (probed on a 4-token answer)."""
+    import oracle
+    from case_rg_amd.utils import fill_params, make_vocab, synth_batch
+    v2i, i2v = make_vocab(a.vocab)
+    m = fill_params(oracle.CaSE(4, a.decode_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers), 1).eval()
+    b = synth_batch(1, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False)
+    host = torch.get_num_threads()
+
+    def run(T):
+        m.max_target_length = T
+        t0 = time.time()
+        with torch.no_grad():
+            m(dict(b), method="test")
+        return time.time() - t0
+
+    by_threads = {}
+    torch.set_num_threads(min(8, host))
+    run(2)
+    for n in _thread_candidates(host):
+        torch.set_num_threads(n)
+        by_threads[str(n)] = round(1.0 / run(4), 3)
+    best = int(max(by_threads, key=lambda k: by_threads[k]))
+    torch.set_num_threads(best)
+    t = run(a.decode_len)
+    torch.set_num_threads(host)
+    return {"value": round(1.0 / t, 4), "unit": "answers/s", "cores": best, "host_cores": host, "kind": "port",
+            "by_threads_4_token_answers_per_s": by_threads,
+            "sample": "fp32 CPU oracle, the reference's O(T^2) greedy loop (prefix re-decoded every step, no KV cache), 1 query x %d passages "
+                      "x %d tokens, %d-token answer, one pass on %d threads (%.1f s)" % (a.passages, a.passage_len, a.decode_len, best, t)}
 
 
 def decode_main(a, device, world, rank):
@@ -350,33 +407,42 @@ def decode_main(a, device, world, rank):
         "roofline": {"bound": "hbm", "kernel": "KV-cached greedy step (cross-attention K/V + additive-attention key streams)",
                      "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,
                      "algorithmic_bytes_per_step": bytes_item_step * a.batch},
+        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
     }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_decode(a)
     if rank == 0:
         print(json.dumps(res))
 
 
-def encoder_main(a, device):
-    """North-star point: CaSE encoder forward, B x P x Lp tokens, fraction of the bf16 MFMA roofline."""
+def encoder_point(a, device, batch=None, steps=None, warmup=None):
+    """North-star point: CaSE encoder forward, B x P x Lp tokens; returns (seconds per forward, algorithmic FLOPs)."""
     import case_rg_amd
     from case_rg_amd.common.CumulativeTrainer import init_params
     from case_rg_amd.common.TransformerSeqEncoderDecoder import TransformerSeqEncoder
     from case_rg_amd.utils import synth_batch
+    batch, steps, warmup = batch or a.batch, steps or a.steps, a.warmup if warmup is None else warmup
     case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     enc = TransformerSeqEncoder(a.enc_layers, 8, a.vocab, a.hidden)
     init_params(enc)
     enc = enc.to(device).eval()
-    ids = synth_batch(a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, ragged=False)["passage"].to(device)
+    ids = synth_batch(batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, ragged=False)["passage"].to(device)
     with torch.no_grad():
-        for _ in range(max(1, a.warmup)):
+        for _ in range(max(1, warmup)):
             enc(ids)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for _ in range(steps):
             enc(ids)
         torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
+    dt = (time.perf_counter() - t0) / steps
+    L, H, n = a.passage_len, a.hidden, batch * a.passages
+    return dt, a.enc_layers * n * (12 * L * H * H + 4 * L * L * H)
+
+
+def encoder_main(a, device):
+    dt, flops = encoder_point(a, device)
     L, H, n = a.passage_len, a.hidden, a.batch * a.passages
-    flops = a.enc_layers * n * (12 * L * H * H + 4 * L * L * H)
     print(json.dumps({"metric": "CaSE encoder forward (north-star point)", "value": round(n * L / dt, 1), "unit": "tokens/s", "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": a.dtype,
                       "data": "synthetic", "config": {"workload": "TransformerSeqEncoder forward, %d layers, d_model %d, %d x %d x %d tokens" % (
@@ -385,10 +451,44 @@ def encoder_main(a, device):
                                    "frac": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_tflop": round(flops / 1e12, 3)}}))
 
 
+def north_star_point(a, device):
+    """The target point of BASELINE.json (encoder forward at batch 64 x 10 passages x 384 tokens, bf16, eval mode), measured in
+    the default run so that the driver's own bench line carries it."""
+    dt, flops = encoder_point(a, device, batch=64, steps=10, warmup=2)
+    return {"workload": "TransformerSeqEncoder forward, %d layers, d_model %d, 64 x %d x %d tokens, bf16, eval" % (
+                a.enc_layers, a.hidden, a.passages, a.passage_len),
+            "batch": 64, "layers": a.enc_layers, "ms": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1),
+            "frac": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "target_frac": 0.5}
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a CHILD process tree and relay its
+    output.  Runs before this process has touched the GPU (torch.cuda.device_count() does not initialise it), and this process
+    never does -- a program that holds the GPU must not be replaced by, or fork, another one on this pool."""
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s)" % (a.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's cross-process buffers need it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and not (world == 1 and a.gpus <= 1):
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch one rank per GPU" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -430,10 +530,12 @@ def main():
         losses = step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [round(elapsed / a.steps * 1e3, 2)]
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([elapsed], device=device, dtype=torch.float64))
+        rank_ms = [round(float(t.item()) / a.steps * 1e3, 2) for t in every]
+        elapsed = max(float(t.item()) for t in every)
 
     tokens_per_step = world * a.batch * (a.query_len + a.passages * a.passage_len)
     value = tokens_per_step * a.steps / elapsed
@@ -451,6 +553,7 @@ def main():
                    "algorithmic_tflop_per_step": round(3 * fwd * world / 1e12, 2)},
         "step_mfma_frac": round(3 * fwd / (elapsed / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "last_losses": [round(x, 4) for x in losses],
+        "world_size": dist.get_world_size() if dist.is_initialized() else 1, "rank_ms_per_step": rank_ms,
     }
     if a.mode == "cfg5":
         out["metric"] += ", cfg 5 long context"
@@ -462,6 +565,10 @@ def main():
         out["roofline"] = roofline_step(a, trainer, opt, sched, batch)
     elif world > 1 and not a.no_roofline:
         step()  # keep the ranks in lock-step with rank 0's instrumented step (it contains an all-reduce)
+    if rank == 0 and world == 1 and a.mode == "train" and a.model == "case" and not a.no_north_star:
+        del trainer, opt, sched  # the training step's parameters, moments and cached operand copies are not needed any more
+        torch.cuda.empty_cache()
+        out["north_star"] = north_star_point(a, device)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "train":
         out["cpu_baseline"] = cpu_baseline(a)
     if rank == 0:

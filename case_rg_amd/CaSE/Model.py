@@ -21,10 +21,8 @@ class CaSETransformerSeqDecoder(PointerDecoderCore):
 
     def __init__(self, num_memories, num_layers, nhead, tgt_vocab_size, hidden_size, emb_matrix=None):
         super().__init__()
-        if emb_matrix is not None:
-            raise NotImplementedError("pre-trained embedding matrices (GloVe) are a data-prep path, out of scope")
         H = hidden_size
-        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, 2 * H)
+        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, 2 * H, emb_matrix=emb_matrix)
         self.norm1 = nn.LayerNorm(H)
         self.norm2 = nn.LayerNorm(H)
         self.gen = nn.Sequential(nn.Linear(3 * H, H), nn.Dropout(0.1), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))

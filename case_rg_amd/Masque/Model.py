@@ -17,10 +17,8 @@ class MasqueTransformerSeqDecoder(PointerDecoderCore):
 
     def __init__(self, num_memories, num_layers, nhead, tgt_vocab_size, hidden_size, emb_matrix=None):
         super().__init__()
-        if emb_matrix is not None:
-            raise NotImplementedError("pre-trained embedding matrices (GloVe) are a data-prep path, out of scope")
         H = hidden_size
-        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H)
+        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H, emb_matrix=emb_matrix)
         self.norm = nn.LayerNorm(H)
         self.gen = nn.Sequential(nn.Linear(2 * H, H), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))
         self.mix = nn.Linear(3 * H, num_memories + 1)

@@ -50,6 +50,23 @@ DROPIN_UTILS = ("neginf", "generate_square_subsequent_mask", "init_seed", "new_t
                 "universal_sentence_embedding", "topk", "to_sentence")
 
 
+def _delegating_topk(ours, theirs):
+    """``topk`` for the caller's ``common.Utils``: the HIP row-argmax for what the CaSE / Masque greedy loop asks (k = 1 on a GPU
+    tensor); every other call -- the reference's own default k = 5 (common/Utils.py:156), ``copy_topk`` (:178), the GLKS / GTTP /
+    S2SA / TMemNet decoders that star-import it, CPU tensors -- keeps going to the caller's original function."""
+    if theirs is None or getattr(theirs, "_case_dropin", False):
+        return ours
+
+    def topk(gen_output, k=5, PAD=None, BOS=None, UNK=None):
+        if k == 1 and getattr(gen_output, "is_cuda", False):
+            return ours(gen_output, k=1, PAD=PAD, BOS=BOS, UNK=UNK)
+        return theirs(gen_output, k=k, PAD=PAD, BOS=BOS, UNK=UNK)
+
+    topk._case_dropin = True
+    topk.__doc__ = _delegating_topk.__doc__
+    return topk
+
+
 def install_dropin():
     """Put the HIP path behind the reference's import paths (CaSE/Run.py:1-11) without touching the rest of its tree.
 
@@ -88,4 +105,7 @@ def install_dropin():
                               "off-path helpers (tokenizers, data preparation) the launch scripts use" % e) from e
         our_utils = importlib.import_module(ours_root + ".common.Utils")
         for name in DROPIN_UTILS:
-            setattr(ref_utils, name, getattr(our_utils, name))
+            if name == "topk":
+                setattr(ref_utils, name, _delegating_topk(our_utils.topk, getattr(ref_utils, "topk", None)))
+            else:
+                setattr(ref_utils, name, getattr(our_utils, name))

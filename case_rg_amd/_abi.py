@@ -82,8 +82,8 @@ SIGNATURES = {
     "case_nll_gather_bwd": [ptr, ptr, ptr, ptr, i64, i64, ptr],
     "case_row_argmax": [ptr, ptr, ptr, i64, i64, i64, ptr],
     "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
-    "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr],
-    "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, f64, f64, f64, ptr],
+    "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
+    "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
 }
 
 

@@ -23,8 +23,16 @@ from .Utils import generate_square_subsequent_mask
 _generate_square_subsequent_mask = generate_square_subsequent_mask
 
 
-def _embedding(vocab, width, max_len=1000):
-    return nn.Sequential(nn.Embedding(vocab, width, padding_idx=0), PositionalEmbedding(width, dropout=0.1, max_len=max_len))
+def _embedding(vocab, width, max_len=1000, emb_matrix=None):
+    """Embedding + position pair.  ``emb_matrix`` [V, H]: a pre-trained table, loaded and frozen as the reference's
+    ``create_emb_layer`` does (common/Utils.py:250-256: ``non_trainable=True``)."""
+    if emb_matrix is not None:
+        vocab, width = emb_matrix.shape
+    table = nn.Embedding(vocab, width, padding_idx=0)
+    if emb_matrix is not None:
+        table.load_state_dict({"weight": emb_matrix})
+        table.weight.requires_grad = False
+    return nn.Sequential(table, PositionalEmbedding(width, dropout=0.1, max_len=max_len))
 
 
 def _embed(seq, ids, training):
@@ -38,10 +46,8 @@ def _embed(seq, ids, training):
 class TransformerSeqEncoder(nn.Module):
     def __init__(self, num_layers, num_heads, src_vocab_size, hidden_size, emb_matrix=None, norm=None):
         super().__init__()
-        if emb_matrix is not None:
-            raise NotImplementedError("pre-trained embedding matrices (GloVe) are a data-prep path, out of scope")
         self.num_layers, self.num_heads = num_layers, num_heads
-        self.embedding = _embedding(src_vocab_size, hidden_size)
+        self.embedding = _embedding(src_vocab_size, hidden_size, emb_matrix=emb_matrix)
         layer = TransformerEncoderLayer(hidden_size, nhead=num_heads, dim_feedforward=hidden_size, dropout=0.1, activation='gelu')
         self.enc = TransformerEncoder(layer, num_layers=num_layers, norm=norm)
 
@@ -59,9 +65,9 @@ class TransformerSeqEncoder(nn.Module):
 class PointerDecoderCore(nn.Module):
     """Shared machinery of the three pointer-generator decoders."""
 
-    def _build(self, num_memories, num_layers, nhead, vocab, H, query_width):
+    def _build(self, num_memories, num_layers, nhead, vocab, H, query_width, emb_matrix=None):
         self.tgt_vocab_size, self.num_layers, self.hidden_size = vocab, num_layers, H
-        self.embedding = _embedding(vocab, H)
+        self.embedding = _embedding(vocab, H, emb_matrix=emb_matrix)
         layer = TransformerDecoderLayer(H, nhead=nhead, dim_feedforward=H, dropout=0.1, activation='gelu')
         self.decs = nn.ModuleList([TransformerDecoder(layer, num_layers=num_layers, norm=None) for _ in range(num_memories)])
         self.attns = nn.ModuleList([BilinearAttention(query_width, H, H) for _ in range(num_memories)])
@@ -190,10 +196,8 @@ class TransformerSeqDecoder(PointerDecoderCore):
 
     def __init__(self, num_memories, num_layers, nhead, tgt_vocab_size, hidden_size, emb_matrix=None):
         super().__init__()
-        if emb_matrix is not None:
-            raise NotImplementedError("pre-trained embedding matrices (GloVe) are a data-prep path, out of scope")
         H = hidden_size
-        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H)
+        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H, emb_matrix=emb_matrix)
         self.norm = nn.LayerNorm(H)
         self.gen = nn.Sequential(nn.Linear(2 * H, H), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))
         self.mix = nn.Linear(H + num_memories * H, num_memories + 1)

@@ -62,36 +62,41 @@ def build_map(b_map, max=None):
 
 
 def universal_sentence_embedding(sentences, mask, sqrt=False):
-    """Masked mean over the sequence axis (reference :455-470; sqrt=False is the only mode used)."""
+    """Masked mean over the sequence axis (reference :455-470); ``sqrt=True`` divides the masked sum by sqrt(count) instead
+    (= mean * sqrt(count); not used on the CaSE / Masque path)."""
+    mean = ops.masked_mean(sentences, mask)
     if sqrt:
-        raise NotImplementedError("sqrt=True is not used on the CaSE path")
-    return ops.masked_mean(sentences, mask)
+        return mean * mask.sum(dim=1).view(-1, 1).to(mean.dtype).sqrt()
+    return mean
 
 
 def topk(gen_output, k=1, PAD=None, BOS=None, UNK=None):
-    """k = 1 greedy pick: (max value, argmax) with the lowest index on ties, keepdim (reference :156-168)."""
-    if k != 1:
-        raise NotImplementedError("greedy (k=1) only on the HIP path")
+    """(values, indices) of the k best columns per row, keepdim (reference :156-168).  k = 1 -- the greedy pick of the CaSE / Masque
+    loop -- is the HIP row-argmax (lowest index on ties, as ``torch.max``); k > 1 is off the hot path and sorts with
+    ``torch.topk`` as the reference does.  Unlike the reference the masked ids are zeroed in a copy, not in the caller's tensor."""
     if PAD is not None or BOS is not None or UNK is not None:
         gen_output = gen_output.clone()
         for tok in (PAD, BOS, UNK):
             if tok is not None:
                 gen_output[:, tok] = 0
+    if k > 1:
+        return torch.topk(gen_output, k, dim=1, largest=True, sorted=True)
     idx, val = ops.row_argmax(gen_output)
     return val.unsqueeze(1), idx.unsqueeze(1)
 
 
-_special_ids = {}
+_special_ids = (None, None)  # (vocabulary object, its special ids): the most recent vocabulary only, compared by identity
 
 
 def _specials(id2vocab):
-    """ids of BOS / PAD / EOS in ``id2vocab`` (-1 when absent), cached per vocabulary object."""
-    key = id(id2vocab)
-    if key not in _special_ids:
+    """ids of BOS / PAD / EOS in ``id2vocab`` (-1 when absent).  Only the most recent vocabulary is remembered, together with
+    the object itself: an ``id()`` key alone would serve stale ids once a freed vocabulary's address is reused by another one."""
+    global _special_ids
+    if _special_ids[0] is not id2vocab:
         items = id2vocab.items() if hasattr(id2vocab, "items") else enumerate(id2vocab)
         inv = {w: i for i, w in items if w in (BOS_WORD, PAD_WORD, EOS_WORD)}
-        _special_ids[key] = tuple(inv.get(w, -1) for w in (BOS_WORD, PAD_WORD, EOS_WORD))
-    return _special_ids[key]
+        _special_ids = (id2vocab, tuple(inv.get(w, -1) for w in (BOS_WORD, PAD_WORD, EOS_WORD)))
+    return _special_ids[1]
 
 
 def to_sentence(batch_indices, id2vocab):

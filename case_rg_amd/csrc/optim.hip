@@ -1,8 +1,13 @@
 // K15  optimizer-side multi-tensor kernels: everything the reference's loop does to the parameters between two backward passes
 // (common/CumulativeTrainer.py:70-76) -- clip_grad_norm_(params, 1), optim.Adam.step(), EMA.update() (common/EMA.py:13-18) --
 // plus the refresh of the bf16 operand copies, as TWO launches over all 365 parameter tensors:
-//   case_optim_sumsq     sum of squares of every gradient (the global L2 norm), f32 atomics into one scalar
-//   case_optim_adam_ema  clip coefficient from that scalar (no host round trip), Adam moments and update, EMA lerp, bf16 copy
+//   case_optim_sumsq     sum of squares of every gradient (the global L2 norm): one partial per chunk, then ONE workgroup adds
+//                        the partials in a fixed order -- the scalar is bit-reproducible run to run and identical on every
+//                        data-parallel rank (f32 atomics from 12k workgroups were neither, and the clip coefficient derived
+//                        from it feeds Adam on every rank: replicas would drift apart in the last ulp)
+//   case_optim_adam_ema  clip coefficient from that scalar (no host round trip), Adam moments and update, EMA lerp, bf16 copy;
+//                        the step-dependent scalars ride in the table entry (torch.optim.Adam keeps a step per parameter), and
+//                        an entry without a gradient only gets its EMA shadow moved (EMA.update touches every parameter)
 // ~7 GB of traffic at H = 512 (p, g, m, v, shadow read; p, m, v, shadow, bf16 written) instead of 6 passes and ~200 launches.
 // The tensors are addressed through a device table (one entry per tensor) and a chunk list (tensor index, chunk index), the
 // usual multi-tensor-apply layout; both are built by the host binding (case_rg_amd/optim.py).
@@ -13,9 +18,13 @@ constexpr int OPT_CHUNK = 16384;  // elements per workgroup
 constexpr int OPT_THREADS = 256;
 
 __global__ __launch_bounds__(OPT_THREADS) void optim_sumsq_kernel(const CaseOptTensor* __restrict__ table, const int32_t* __restrict__ chunks,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ partials) {
   __shared__ float red[32];
   const CaseOptTensor t = table[chunks[2 * blockIdx.x]];
+  if (t.g == nullptr) {  // shadow-only entry (a parameter that received no gradient this step)
+    if (threadIdx.x == 0) partials[blockIdx.x] = 0.f;
+    return;
+  }
   const int64_t begin = (int64_t)chunks[2 * blockIdx.x + 1] * OPT_CHUNK;
   const int64_t end = begin + OPT_CHUNK < t.numel ? begin + OPT_CHUNK : t.numel;
   const float* g = reinterpret_cast<const float*>(t.g) + begin;
@@ -32,21 +41,34 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_sumsq_kernel(const CaseOptT
     for (int64_t i = threadIdx.x; i < n; i += OPT_THREADS) s += g[i] * g[i];
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// fixed-order sum of the per-chunk partials: thread t adds partials[t], [t + 1024], ... in index order, then the block tree
+constexpr int OPT_FINAL_THREADS = 1024;
+__global__ __launch_bounds__(OPT_FINAL_THREADS) void optim_sumsq_final_kernel(const float* __restrict__ partials, int64_t n,
+                                                                              float* __restrict__ out) {
+  __shared__ float red[32];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += OPT_FINAL_THREADS) s += partials[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *out = s;
 }
 
 struct AdamArgs {
   const float* sumsq;  // null: no clipping
-  // derived on the host in double, as torch's _single_tensor_adam does: 1 - beta1, 1 - beta2, lr / (1 - beta1^t), sqrt(1 - beta2^t)
-  float max_norm, one_m_b1, beta2, one_m_b2, eps, step_size, bc2_sqrt, ema_w;
+  // derived on the host in double, as torch's _single_tensor_adam does: 1 - beta1, 1 - beta2; the step-dependent lr / (1 - beta1^t)
+  // and sqrt(1 - beta2^t) are per tensor (CaseOptTensor.step_size / .bc2_sqrt)
+  float max_norm, one_m_b1, beta2, one_m_b2, eps, ema_w;
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float clip) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float clip, float step_size,
+                                         float bc2_sqrt) {
   g *= clip;
   m = m + a.one_m_b1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
   v = a.beta2 * v + a.one_m_b2 * (g * g);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  p -= a.step_size * (m / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+  const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+  p -= step_size * (m / denom);                    // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 __global__ __launch_bounds__(OPT_THREADS) void optim_adam_ema_kernel(const CaseOptTensor* __restrict__ table, const int32_t* __restrict__ chunks,
@@ -62,9 +84,14 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_adam_ema_kernel(const CaseO
   float* v = reinterpret_cast<float*>(t.v);
   float* sh = reinterpret_cast<float*>(t.shadow);
   bf16_t* lp = reinterpret_cast<bf16_t*>(t.p_bf16);
+  if (g == nullptr) {  // no gradient this step: the parameter and its moments stay, the EMA shadow still moves (common/EMA.py:13-18)
+    if (sh && a.ema_w > 0.f)
+      for (int64_t i = begin + threadIdx.x; i < end; i += OPT_THREADS) sh[i] = sh[i] + a.ema_w * (p[i] - sh[i]);
+    return;
+  }
   for (int64_t i = begin + threadIdx.x; i < end; i += OPT_THREADS) {
     float pi = p[i], mi = m[i], vi = v[i];
-    adam_one(pi, g[i], mi, vi, a, clip);
+    adam_one(pi, g[i], mi, vi, a, clip, t.step_size, t.bc2_sqrt);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
@@ -74,19 +101,19 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_adam_ema_kernel(const CaseO
 }
 }  // namespace
 
-extern "C" int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* sumsq, case_stream_t stream) {
-  CASE_REQUIRE(table && chunks && sumsq && nchunks > 0 && nchunks < (1ll << 31), "case_optim_sumsq: bad argument");
-  hipLaunchKernelGGL(optim_sumsq_kernel, dim3((unsigned)nchunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, table, chunks, sumsq);
+extern "C" int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* partials, float* sumsq,
+                                case_stream_t stream) {
+  CASE_REQUIRE(table && chunks && partials && sumsq && nchunks > 0 && nchunks < (1ll << 31), "case_optim_sumsq: bad argument");
+  hipLaunchKernelGGL(optim_sumsq_kernel, dim3((unsigned)nchunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, table, chunks, partials);
+  hipLaunchKernelGGL(optim_sumsq_final_kernel, dim3(1), dim3(OPT_FINAL_THREADS), 0, (hipStream_t)stream, partials, nchunks, sumsq);
   return case_check_launch("case_optim_sumsq");
 }
 
 extern "C" int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
-                                   double lr, double beta1, double beta2, double eps, double bias_c1, double bias_c2, double ema_w,
-                                   case_stream_t stream) {
+                                   double beta1, double beta2, double eps, double ema_w, case_stream_t stream) {
   CASE_REQUIRE(table && chunks && nchunks > 0 && nchunks < (1ll << 31), "case_optim_adam_ema: bad argument");
-  CASE_REQUIRE(bias_c1 > 0. && bias_c2 > 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., "case_optim_adam_ema: bad hyper-parameters");
-  const AdamArgs a = {sumsq, max_norm, (float)(1. - beta1), (float)beta2, (float)(1. - beta2), (float)eps, (float)(lr / bias_c1),
-                      (float)sqrt(bias_c2), (float)ema_w};
+  CASE_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., "case_optim_adam_ema: bad hyper-parameters");
+  const AdamArgs a = {sumsq, max_norm, (float)(1. - beta1), (float)beta2, (float)(1. - beta2), (float)eps, (float)ema_w};
   hipLaunchKernelGGL(optim_adam_ema_kernel, dim3((unsigned)nchunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, table, chunks, a);
   return case_check_launch("case_optim_adam_ema");
 }

@@ -7,6 +7,7 @@ update (common/EMA.py:13-18) and the refresh of the bf16 operand copies the kern
 runs the reference's three separate calls.  State (exp_avg, exp_avg_sq, step) lives in ``self.state`` like torch's, so
 ``state_dict`` / ``load_state_dict`` and the resumable checkpoint work unchanged."""
 import ctypes as C
+import math
 
 import torch
 
@@ -16,7 +17,7 @@ from . import ops
 
 class _Entry(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p),
-                ("p_bf16", C.c_void_p), ("numel", C.c_int64)]
+                ("p_bf16", C.c_void_p), ("numel", C.c_int64), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -29,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._chunks = {}
         self._table = (None, None)  # (host bytes, device copy): re-uploaded only when a pointer moved
         self._low = {}  # id(parameter) -> its operand copy, rewritten in place by every step
+        self._norm_ws = None  # f32 [1 + chunks]: squared gradient norm + its per-chunk partials
 
     def _chunk_list(self, numels, device):
         key = (tuple(numels), str(device))
@@ -51,16 +53,20 @@ class FusedAdam(torch.optim.Optimizer):
             names = {id(p): n for n, p in ema.model.named_parameters()}
             shadow_of = {pid: ema.shadow[n] for pid, n in names.items() if n in ema.shadow}
         for group in self.param_groups:
+            # parameters with a gradient take the Adam update; those without one (unused this step: the reference builds DDP with
+            # find_unused_parameters=True, and Masque alternates 'ps_train' / 'train') only have their EMA shadow moved, as
+            # EMA.update() does for every trainable parameter (common/EMA.py:13-18)
             params = [p for p in group["params"] if p.grad is not None]
+            idle = [p for p in group["params"] if p.grad is None and p.requires_grad and id(p) in shadow_of]
             if not params:
                 continue
             dev = params[0].device
             if not params[0].is_cuda:
                 raise RuntimeError("case_rg_amd.optim.FusedAdam runs on the GPU only; there is no CPU path")
             beta1, beta2 = group["betas"]
-            entries = (_Entry * len(params))()
+            lr = float(group["lr"])
+            entries = (_Entry * (len(params) + len(idle)))()
             fresh = {}
-            steps = set()
             for i, p in enumerate(params):
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous():
                     raise TypeError("FusedAdam expects contiguous float32 parameters and gradients")
@@ -69,8 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = int(st["step"]) + 1
-                steps.add(st["step"])
+                step = st["step"] = int(st["step"]) + 1  # one step count per parameter, as torch.optim.Adam keeps
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 sh = shadow_of.get(id(p))
                 lp = None
@@ -80,24 +85,28 @@ class FusedAdam(torch.optim.Optimizer):
                         lp = self._low[id(p)] = torch.empty(p.shape, dtype=self.low_precision, device=dev)
                     fresh[id(p)] = lp
                 entries[i] = _Entry(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                    0 if sh is None else sh.data_ptr(), 0 if lp is None else lp.data_ptr(), p.numel())
+                                    0 if sh is None else sh.data_ptr(), 0 if lp is None else lp.data_ptr(), p.numel(),
+                                    lr / (1.0 - beta1 ** step), math.sqrt(1.0 - beta2 ** step))
                 st["_g"] = g  # keep a non-contiguous gradient's copy alive until the launch has consumed it
-            if len(steps) != 1:
-                raise RuntimeError("FusedAdam: parameters of one group must share their step count")
-            step = steps.pop()
+            for j, p in enumerate(idle):
+                entries[len(params) + j] = _Entry(p.data_ptr(), 0, 0, 0, shadow_of[id(p)].data_ptr(), 0, p.numel(), 0.0, 1.0)
             raw = bytes(entries)
             if self._table[0] != raw or self._table[1].device != dev:
                 self._table = (raw, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
             table = self._table[1]
-            chunks = self._chunk_list([p.numel() for p in params], dev)
+            chunks = self._chunk_list([p.numel() for p in params + idle], dev)
             stream = torch.cuda.current_stream().cuda_stream
             sumsq = None
             if clip_norm is not None:
-                sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-                A.call("case_optim_sumsq", table.data_ptr(), chunks.data_ptr(), chunks.shape[0], sumsq.data_ptr(), stream)
+                # [0] the squared global norm, [1:] one partial per chunk, summed in a fixed order by one workgroup: the clip
+                # coefficient is bit-identical on every data-parallel rank (and run to run)
+                if self._norm_ws is None or self._norm_ws.numel() != chunks.shape[0] + 1 or self._norm_ws.device != dev:
+                    self._norm_ws = torch.empty(chunks.shape[0] + 1, dtype=torch.float32, device=dev)
+                sumsq = self._norm_ws
+                A.call("case_optim_sumsq", table.data_ptr(), chunks.data_ptr(), chunks.shape[0], sumsq.data_ptr() + 4, sumsq.data_ptr(),
+                       stream)
             A.call("case_optim_adam_ema", table.data_ptr(), chunks.data_ptr(), chunks.shape[0], None if sumsq is None else sumsq.data_ptr(),
-                   float(clip_norm or 0.0), float(group["lr"]), beta1, beta2, group["eps"], 1.0 - beta1 ** step, 1.0 - beta2 ** step,
-                   0.0 if ema is None else 1.0 - ema.decay, stream)
+                   float(clip_norm or 0.0), beta1, beta2, group["eps"], 0.0 if ema is None else 1.0 - ema.decay, stream)
             for p in params:
                 self.state[p].pop("_g", None)
             # the kernel wrote the parameters behind autograd's back (_version did not move): drop every cached operand copy and

@@ -308,11 +308,15 @@ int case_row_argmax(const float* x, int64_t* idx, float* val, int64_t rows, int6
  *   optim.Adam.step() (CaSE/Run.py:27: default betas / eps, no weight decay) -> EMA.update() (common/EMA.py:13-18), plus the
  *   refresh of the bf16 operand copies, in two launches over all parameter tensors.
  * `table` (device): one CaseOptTensor per tensor, f32 p / g / m (exp_avg) / v (exp_avg_sq) / shadow (EMA, may be null),
- *   p_bf16 (may be null), numel.  `chunks` (device): int32 pairs (tensor index, chunk index), one per workgroup, chunk =
- *   case_optim_chunk_elems() elements.  sumsq: pre-zeroed f32 scalar; pass it to case_optim_adam_ema to apply the clip
- *   coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) without a host round trip (null: no clipping).
- * bias_c1 = 1 - beta1^step, bias_c2 = 1 - beta2^step (host scalars; the derived step size lr / bias_c1, sqrt(bias_c2), 1 - beta are
- *   formed in double and rounded to f32 once, as torch.optim.Adam does); ema_w = 1 - decay (0: no EMA update).
+ *   p_bf16 (may be null), numel, and the tensor's step-dependent scalars step_size = lr / (1 - beta1^step), bc2_sqrt =
+ *   sqrt(1 - beta2^step) (torch.optim.Adam keeps one step count per parameter; formed in double on the host and rounded to f32
+ *   once, as torch does).  An entry with g == null is a parameter without a gradient this step: only its EMA shadow moves
+ *   (common/EMA.py:13-18 touches every trainable parameter).  `chunks` (device): int32 pairs (tensor index, chunk index), one
+ *   per workgroup, chunk = case_optim_chunk_elems() elements.
+ * case_optim_sumsq: partials f32 [nchunks] (workspace) receives one sum of squares per chunk; sumsq (f32 scalar) their sum,
+ *   added by one workgroup in a fixed order: bit-reproducible and identical on every data-parallel rank, like the reference's
+ *   clip_grad_norm_.  Pass sumsq to case_optim_adam_ema to apply the clip coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6))
+ *   without a host round trip (null: no clipping).  ema_w = 1 - decay (0: no EMA update).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   void* p;
@@ -322,12 +326,14 @@ typedef struct {
   void* shadow;
   void* p_bf16;
   int64_t numel;
+  float step_size;
+  float bc2_sqrt;
 } CaseOptTensor;
 int case_optim_chunk_elems(void);
-int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* sumsq, case_stream_t stream);
+int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* partials, float* sumsq,
+                     case_stream_t stream);
 int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
-                        double lr, double beta1, double beta2, double eps, double bias_c1, double bias_c2, double ema_w,
-                        case_stream_t stream);
+                        double beta1, double beta2, double eps, double ema_w, case_stream_t stream);
 
 /* Greedy post-processing on the device (common/Utils.py:200-217 to_sentence): per row of ids [B, T] drop the BOS / PAD ids and
  * everything from the first EOS on; out [B, T] holds the kept ids front-packed (pad behind), len [B] their count.  One host

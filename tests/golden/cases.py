@@ -567,6 +567,87 @@ def case_prod_masque_train(ns, dev):
 
 
 # ---------------------------------------------------------------------------------------------
+# greedy decoding at PRODUCTION geometry (BASELINE cfg 4 shapes per item: H 512, 8 heads of 64, Lp 384, Lq 64, V 30522): the
+# reference's own O(T^2) loop (CaSE/Model.py:91-123, Masque/Model.py:85-117) on two queries x two passages, T = 14 steps.  On
+# the GPU this reaches what `bench.py --mode decode` times -- attn_decode64_kernel (head_dim 64 against the cached K / V of the
+# 768- and 64-token memories), bf16 gemm_small at M = batch, the T = 1 additive-attention rows, the sorted pointer scatter --
+# which the toy-geometry greedy fixtures (head_dim 4, f32) never do.
+# ---------------------------------------------------------------------------------------------
+PROD_T = 14
+
+
+def _prod_test_batch(dev, seed, model):
+    b = synth_batch(2, 2, 384, 64, PROD_T, PROD_V, seed=seed, model=model)  # ragged lengths + one filler passage per item
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def _prod_test_model(ns, dev, seed, model, gain):
+    """``gain`` = (global weight gain, extra gain on the pointer heads' ``v`` vectors, extra gain on the vocabulary projection).
+    A large GLOBAL gain makes a 20-layer random network chaotic (f32 op-order differences reach 1e-3 on the rank logits at
+    gain 7), so the decisiveness comes from the last linear maps in front of the softmaxes instead: errors upstream are not
+    amplified through the depth of the network, only scaled once."""
+    v2i, i2v = make_vocab(PROD_V)
+    m = ns.CaSE(4, PROD_T, i2v, v2i, 512) if model == "case" else ns.Masque(PROD_T, i2v, v2i, 512)
+    m = _mod(m, seed, dev, gain=gain[0])
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.startswith("response_generation.decoder.attns.") and n.endswith(".v.weight"):
+                p.mul_(gain[1])
+            if n in ("response_generation.decoder.gen.2.weight", "response_generation.decoder.gen.1.weight"):
+                p.mul_(gain[2])
+    return m
+
+
+def _top2(dist):
+    """(top1 - top2 probability, top1 probability, top1 id) per step of a teacher-forced pass over the greedy answer."""
+    top = dist.float().topk(2, dim=-1)
+    return top[0][..., 0] - top[0][..., 1], top[0][..., 0], top[1][..., 0]
+
+
+def case_prod_case_test(ns, dev):
+    m = _prod_test_model(ns, dev, 311, "case", PROD_TEST_GAIN["case"])
+    b = _prod_test_batch(dev, 312, "case")
+    out = _greedy(m, b)
+    rec = {"in_" + k: v for k, v in b.items() if k in ("query", "passage", "source_map")}
+    rec.update({"answer": out["answer"], "rank": out["rank"]})
+    m.train()
+    with torch.no_grad():
+        q, p = b["query"], b["passage"]
+        eq, ep = m.query_encoder(q), m.passage_encoder(p)
+        ps = m.passage_selection.action(q, p, encode_query=eq, encode_passage=ep)
+        se = m.span_extraction.action(q, p, encode_query=eq, encode_passage=ep, passage_selection_result=ps)
+        rg = m.response_generation.action(q, p, ns.build_map(b["source_map"], max=PROD_V), encode_query=eq, encode_passage=ep,
+                                          passage_selection_result=ps, span_extraction_result=se, output=out["answer"])
+        rec["margin"], rec["top1_prob"], rec["top1_id"] = _top2(rg[2][0] + rg[2][1])
+    return rec
+
+
+def case_prod_masque_test(ns, dev):
+    m = _prod_test_model(ns, dev, 321, "masque", PROD_TEST_GAIN["masque"])
+    b = _prod_test_batch(dev, 322, "masque")
+    out = _greedy(m, b)
+    rec = {"in_" + k: v for k, v in b.items() if k in ("query", "passage", "source_map")}
+    rec.update({"answer": out["answer"], "rank": out["rank"]})
+    m.train()
+    with torch.no_grad():
+        q, p = b["query"], b["passage"]
+        eq, ep = m.query_encoder(q)[0][:, :, -1], m.passage_encoder(p)[0][:, :, -1]
+        ps = m.passage_selection.action(q, p, encode_query=eq, encode_passage=ep)
+        rg = m.response_generation.action(q, p, ns.build_map(b["source_map"], max=PROD_V), encode_query=eq, encode_passage=ep,
+                                          passage_selection_result=ps, output=out["answer"])
+        rec["margin"], rec["top1_prob"], rec["top1_id"] = _top2(rg[2])
+    return rec
+
+
+# (global, pointer-head v, vocabulary projection) gains, scanned in the build container.  Global gains of 5-10 give answers with
+# 10-14 distinct ids but make the 20-layer random network chaotic (reference vs oracle, both f32 on the CPU, already differ by
+# 6e-4 on the rank logits at gain 7); with the decisiveness in the last maps the answers are less varied (1-3 distinct ids) but
+# every step's top-1 probability and top1 - top2 margin (0.01-0.43 for CaSE, 0.19 / 0.42 for Masque) is compared numerically, and
+# those depend on every cached position of the prefix.
+PROD_TEST_GAIN = {"case": (2.0, 40.0, 4.0), "masque": (2.0, 40.0, 4.0)}
+
+
+# ---------------------------------------------------------------------------------------------
 # BASELINE cfg 5 geometry (d_model 768 -> head_dim 96 and 480, Lp = 512, decoder memory S = 40 x 512 = 20 480)
 # ---------------------------------------------------------------------------------------------
 def _cfg5_block(ns, dev, seed, width_in):
@@ -616,4 +697,5 @@ def case_cfg5_dec_layer_long_memory(ns, dev):
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
 PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory")
+PROD_TEST_CASES = ("prod_case_test", "prod_masque_test")  # greedy decoding at production geometry
 PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too

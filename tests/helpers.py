@@ -35,13 +35,16 @@ def compare(name, got, want, rtol, atol):
     return worst
 
 
-def check_case(name, rec, rtol, atol, grad_rtol=None, grad_atol=None, skip=()):
+def check_case(name, rec, rtol, atol, grad_rtol=None, grad_atol=None, skip=(), override=None):
+    """``override``: {key: (rtol, atol)} for single tensors that carry a documented looser bar."""
     golden = load_golden(name)
     assert set(rec) == set(golden), "case %s: keys differ: %s" % (name, set(rec) ^ set(golden))
     for k, want in golden.items():
         if k in skip:
             continue
-        if k.startswith("in_"):  # regenerated inputs must be the committed inputs
+        if override and k in override:
+            compare(name + "/" + k, rec[k], want, *override[k])
+        elif k.startswith("in_"):  # regenerated inputs must be the committed inputs
             compare(name + "/" + k, rec[k], want, 0.0, 0.0)
         elif k.startswith("g"):
             compare(name + "/" + k, rec[k], want, grad_rtol or rtol, grad_atol or atol)

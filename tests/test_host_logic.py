@@ -164,9 +164,17 @@ def test_install_dropin_under_the_reference_run_py_imports(model):
         for k, v in names.items():
             print(k, v.__module__)
         print("constants", common.Constants.__file__)
+        # the reference's own callers of topk (default k = 5, copy_topk, the baselines' decoders) still get ITS behaviour
+        import common.Utils as CU
+        x = torch.tensor([[0.1, 0.7, 0.06, 0.05, 0.04, 0.03, 0.02]])
+        v5, i5 = CU.topk(x.clone())
+        print("topk5", ",".join(str(int(i)) for i in i5[0]), tuple(v5.shape)[1])
+        v1, i1 = CU.topk(x.clone(), k=1)
+        print("topk1", int(i1[0, 0]), tuple(i1.shape)[1])
         """.replace("{M}", model).replace("{D}", ds) % (ROOT, REF))
-    got = dict(line.split() for line in out.strip().splitlines())
+    got = dict(line.split(None, 1) for line in out.strip().splitlines())
     hip = "case_rg_amd."
+    assert got["topk5"] == "1,0,2,3,4 5" and got["topk1"] == "1 1"
     assert got["dataset"] == "%s.%s" % (model, ds) and got["collate_fn"] == "%s.%s" % (model, ds)
     assert got["bert_tokenizer"] == "common.Utils" and got["bert_detokenizer"] == "common.Utils"
     assert got["save_result"] == "Utils" and got["greedy"] == "common.Generations"
@@ -175,6 +183,18 @@ def test_install_dropin_under_the_reference_run_py_imports(model):
     assert got["trainer"] == hip + "common.CumulativeTrainer" and got["init_params"] == hip + "common.CumulativeTrainer"
     assert got["init_seed"] == hip + "common.Utils" and got["build_map"] == hip + "common.Utils"
     assert got["block"] == hip + "common.TransformerBlock" and got["inter"] == hip + "common.Interaction"
+
+
+def test_special_id_cache_follows_the_vocabulary_object():
+    """to_sentence's BOS / PAD / EOS ids are remembered for the most recent vocabulary OBJECT (identity, not id())."""
+    from case_rg_amd.common import Utils
+    from case_rg_amd.common.Constants import BOS_WORD, EOS_WORD, PAD_WORD
+    a = {0: PAD_WORD, 1: BOS_WORD, 2: EOS_WORD, 3: "x"}
+    b = {0: "x", 5: PAD_WORD, 6: BOS_WORD, 7: EOS_WORD}
+    assert Utils._specials(a) == (1, 0, 2)
+    assert Utils._specials(b) == (6, 5, 7) and Utils._special_ids[0] is b
+    assert Utils._specials(a) == (1, 0, 2)
+    assert Utils._specials(["x", "y"]) == (-1, -1, -1)
 
 
 def test_bench_flop_model_matches_the_survey():

@@ -105,3 +105,64 @@ def test_trainer_with_fused_adam_follows_the_unfused_loop():
     for n in pa:
         assert torch.allclose(pa[n], pb[n], rtol=1e-3, atol=2e-5), (n, (pa[n] - pb[n]).abs().max().item())
         assert torch.allclose(ea[n], eb[n], rtol=1e-4, atol=1e-6), n
+
+
+def test_fused_adam_keeps_a_step_per_parameter_and_moves_the_shadow_of_idle_ones():
+    """A parameter whose gradient is None on some steps (Masque alternating 'ps_train' / 'train', data-dependent branches): torch.optim.Adam
+    skips it and keeps its own step count; the reference's EMA.update() still lerps its shadow (common/EMA.py:13-18)."""
+    from case_rg_amd.common.EMA import EMA
+    from case_rg_amd.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    ma, mb = _Holder(_params(dev, 9)), _Holder(_params(dev, 9))
+    ea, eb = EMA(ma, 0.9), EMA(mb, 0.9)
+    ea.register(), eb.register()
+    oa = FusedAdam(ma.parameters(), lr=1e-2, low_precision=torch.bfloat16)
+    ob = torch.optim.Adam(mb.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(6)
+    for step in range(5):
+        for i, (pa, pb) in enumerate(zip(ma.parameters(), mb.parameters())):
+            gr = torch.randn(pa.shape, generator=g).to(dev) * 0.1
+            idle = (i in (1, 3) and step in (0, 2)) or (i == 4 and step < 3)  # late first gradient, gaps
+            pa.grad, pb.grad = (None, None) if idle else (gr.clone(), gr.clone())
+        oa.step(clip_norm=1.0, ema=ea)
+        torch.nn.utils.clip_grad_norm_(mb.parameters(), 1.0)
+        ob.step()
+        eb.update()
+        for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7), (step, n, (pa - pb).abs().max().item())
+            assert torch.allclose(ea.shadow[n], eb.shadow[n], rtol=1e-6, atol=1e-7), (step, n)
+            if pb in ob.state and ob.state[pb]:
+                assert oa.state[pa]["step"] == int(ob.state[pb]["step"]), (step, n)
+
+
+def test_fused_adam_clip_is_bit_reproducible():
+    """The squared gradient norm is a fixed-order sum (per-chunk partials, then one workgroup): the clip coefficient -- and so every
+    updated parameter -- is bit-identical run to run and across data-parallel ranks holding the same reduced gradients, whatever else
+    the GPU is doing (f32 atomics into one scalar were not)."""
+    from case_rg_amd.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(12)
+    shapes = [(30522, 64), (2560, 2560), (777,), (512, 512), (3,)]
+    init = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    grads = [(torch.randn(s, generator=g) * 3.0).to(dev) for s in shapes]
+    side = torch.cuda.Stream()
+    noise = torch.randn(4096, 4096, device=dev)
+    results = []
+    for run in range(4):
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        opt = FusedAdam(ps, lr=1e-2)
+        if run % 2:  # perturb workgroup scheduling with a concurrent kernel stream
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    noise = noise @ noise * 1e-4
+        for _ in range(3):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone()
+            opt.step(clip_norm=1.0)
+        torch.cuda.synchronize()
+        results.append(([p.detach().clone() for p in ps], opt._norm_ws[0].item()))
+    for ps, nrm in results[1:]:
+        assert nrm == results[0][1]
+        assert all(torch.equal(a, b) for a, b in zip(ps, results[0][0]))
+    want = sum(float((gr.double() ** 2).sum()) for gr in grads)
+    assert abs(results[0][1] - want) <= 1e-5 * want

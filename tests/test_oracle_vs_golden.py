@@ -21,6 +21,11 @@ def _oracle_ns():
 @pytest.mark.parametrize("name", list(cases.CASES))
 def test_oracle_matches_reference_fixture(name):
     rec = cases.CASES[name](_oracle_ns(), torch.device("cpu"))
+    if name in cases.PROD_TEST_CASES:
+        # probabilities behind 40x-sharpened pointer logits (cases.PROD_TEST_GAIN): f32 summation-order noise of 1e-5 on a logit
+        # of magnitude 30 is 1e-4 on the probability; ids, inputs and the rank logits keep the tight bar
+        check_case(name, rec, rtol=2e-5, atol=2e-6, override={"margin": (3e-4, 2e-6), "top1_prob": (3e-4, 2e-6)})
+        return
     check_case(name, rec, rtol=2e-5, atol=2e-6, grad_rtol=1e-4, grad_atol=1e-5)
 
 

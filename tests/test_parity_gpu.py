@@ -51,7 +51,7 @@ def _check(name, rec, tol=1e-3, grad_tol=1e-3):
             _scaled_close(name + "/" + k, got, want, grad_tol if k.startswith("g") else tol)
 
 
-MODULE_CASES = [n for n in cases.CASES if n not in cases.MODEL_CASES + cases.PROD_CASES + cases.PROD_FORWARD_CASES]
+MODULE_CASES = [n for n in cases.CASES if n not in cases.MODEL_CASES + cases.PROD_CASES + cases.PROD_FORWARD_CASES + cases.PROD_TEST_CASES]
 
 
 @pytest.mark.parametrize("name", MODULE_CASES)
