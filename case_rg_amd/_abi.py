@@ -26,6 +26,10 @@ class GemmDesc(C.Structure):
                [("alpha", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
 
 
+class EncoderChainDesc(C.Structure):
+    _fields_ = [("rows", i64), ("width", i32), ("variant", i32), ("eps_ln2", f32), ("eps_ln1_next", f32)]
+
+
 class SoftmaxDesc(C.Structure):
     _fields_ = [("outer", i64), ("inner", i64), ("R", i64), ("C", i64), ("causal", i32), ("in_dtype", i32),
                 ("out_dtype", i32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
@@ -82,6 +86,8 @@ SIGNATURES = {
     "case_nll_gather_bwd": [ptr, ptr, ptr, ptr, i64, i64, ptr],
     "case_row_argmax": [ptr, ptr, ptr, i64, i64, i64, ptr],
     "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
+    "case_encoder_chain_pack": [ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_encoder_chain": [C.POINTER(EncoderChainDesc)] + [ptr] * 15,
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
     "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
 }
@@ -99,6 +105,9 @@ def _load():
         fn.restype = C.c_int
     lib.case_optim_chunk_elems.restype = C.c_int
     lib.case_optim_chunk_elems.argtypes = []
+    for fn in (lib.case_encoder_chain_packed_bytes, lib.case_encoder_chain_scratch_bytes):
+        fn.restype = C.c_int64
+        fn.argtypes = []
     lib.case_version.restype = C.c_int
     lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()
     lib.case_gemm_tile_for.argtypes = [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr]

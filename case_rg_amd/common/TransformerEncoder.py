@@ -7,6 +7,7 @@ epilogue) -> LayerNorm kernel -> FFN GEMM pair (bias+activation+dropout / bias+d
 """
 import copy
 
+import torch
 import torch.nn as nn
 
 from .. import config, ops
@@ -57,9 +58,30 @@ class TransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
+    def _chained(self, x, valid):
+        """Inference form: the row-local half of every layer (out-proj + residual -> LN2 -> FFN -> + residual -> next LN1 -> next QKV) is
+        ONE kernel per layer (ops.encoder_chain, csrc/encoder_chain.hip); only the attention core runs between two of them."""
+        layers = list(self.layers)
+        s, qkv = ops.encoder_chain("head", x, None, None, layers[0])
+        for i, layer in enumerate(layers):
+            at = layer.self_attn
+            ctx = ops.attention(qkv, qkv, qkv, 0, at.embed_dim, 2 * at.embed_dim, at.num_heads, at.head_dim, key_valid=valid)
+            if i + 1 < len(layers):
+                s, qkv = ops.encoder_chain("full", ctx, s, layer, layers[i + 1])
+            else:
+                s, qkv = ops.encoder_chain("tail", ctx, s, layer, None)
+        return s
+
     def forward_batch_first(self, x, valid=None, causal=False):
-        for layer in self.layers:
-            x = layer.forward_batch_first(x, valid, causal)
+        first = self.layers[0]
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if (not causal and not self.training and all(l.activation == "gelu" for l in self.layers)
+                and ops.encoder_chain_supported(x, first.self_attn.embed_dim, first.linear1.out_features, needs_grad)
+                and all(l.self_attn.embed_dim == 512 and l.linear1.out_features == 512 and l.self_attn.head_dim == 64 for l in self.layers)):
+            x = self._chained(x, valid)
+        else:
+            for layer in self.layers:
+                x = layer.forward_batch_first(x, valid, causal)
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x

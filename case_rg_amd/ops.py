@@ -50,10 +50,11 @@ _cast_cache = {}
 
 
 def invalidate_param_cache():
-    """Forget every cached low-precision parameter copy.  ``_version`` does not move when a parameter is rewritten through
+    """Forget every cached low-precision parameter copy (and the fragment-ordered weight packs of the fused encoder chain).  ``_version`` does not move when a parameter is rewritten through
     ``.data`` (``p.data = t``, ``p.data.copy_()``, ``xavier_uniform_(p.data)``, ``dist.broadcast(p.data)``), so the code paths
     that do that -- ``EMA.apply_shadow`` / ``restore``, ``GradSync.broadcast_parameters``, ``init_params`` -- call this."""
     _cast_cache.clear()
+    _chain_packs.clear()
 
 
 def seed_param_cache(p, low):
@@ -106,6 +107,70 @@ def cast(x, dtype):
     out = torch.empty(x.shape, dtype=dtype, device=x.device)
     A.call("case_cast", _ptr(x), _ptr(out), x.numel(), _code(x), _DT[dtype], _stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# K16 fused encoder chain (inference): out-proj + residual -> LN2 -> FFN1 + GELU -> FFN2 + residual -> next LN1 -> next QKV
+# ----------------------------------------------------------------------------------------------
+# "auto": the chain runs wherever it is built (bf16, d_model = dim_feedforward = 512, no autograd, no dropout); "off": the
+# single-launch path (tests replay the same fixtures under both; A/B measurements)
+ENCODER_CHAIN = "auto"
+_chain_packs = {}
+_chain_scratch = {}
+
+
+def encoder_chain_supported(x, width, ffn_width, needs_grad):
+    return (ENCODER_CHAIN == "auto" and x.is_cuda and x.dtype == torch.bfloat16 and width == 512 and ffn_width == 512
+            and not needs_grad)
+
+
+def _chain_pack(mats):
+    """Fragment-ordered bf16 pack of (Wo, W1, W2, Wqkv_next) -- any of them None -- cached until one of the parameters changes."""
+    key = tuple(0 if m is None else id(m) for m in mats)
+    stamp = tuple(None if m is None else (m._version, m.data_ptr()) for m in mats)
+    hit = _chain_packs.get(key)
+    if hit is not None and hit[0] == stamp and all((r is None) == (m is None) and (r is None or r() is m) for r, m in zip(hit[1], mats)):
+        return hit[2]
+    dev = next(m for m in mats if m is not None).device
+    low = [None if m is None else cast_param(m, torch.bfloat16) for m in mats]
+    packed = torch.empty(A.lib.case_encoder_chain_packed_bytes() // 2, dtype=torch.bfloat16, device=dev)
+    A.call("case_encoder_chain_pack", _ptr(low[0]), _ptr(low[1]), _ptr(low[2]), _ptr(low[3]), _ptr(packed), _stream())
+    _chain_packs[key] = (stamp, [None if m is None else weakref.ref(m) for m in mats], packed)
+    return packed
+
+
+def encoder_chain(variant, x_in, resid, layer, next_layer):
+    """One launch of the row-local chain (csrc/encoder_chain.hip).  variant "head": x_in = embedding output, ``next_layer``'s norm1 +
+    in-projection -> (s, qkv); "full": x_in = ``layer``'s attention output, resid = its normed input -> (s', qkv') for
+    ``next_layer``; "tail": the last layer -> its output.  ``layer`` / ``next_layer`` are TransformerEncoderLayer modules."""
+    M = x_in.shape[0] * x_in.shape[1]
+    dev = x_in.device
+    f32 = lambda p: None if p is None else p.detach()
+    lay = None if variant == "head" else layer
+    nxt = None if variant == "tail" else next_layer
+    packed = _chain_pack((None if lay is None else lay.self_attn.out_proj.weight, None if lay is None else lay.linear1.weight,
+                          None if lay is None else lay.linear2.weight, None if nxt is None else nxt.self_attn.in_proj_weight))
+    d = A.EncoderChainDesc()
+    d.rows, d.width, d.variant = M, 512, {"full": 0, "tail": 1, "head": 2}[variant]
+    d.eps_ln2 = 0.0 if lay is None else lay.norm2.eps
+    d.eps_ln1_next = 0.0 if nxt is None else nxt.norm1.eps
+    s_out = torch.empty(x_in.shape, dtype=torch.bfloat16, device=dev)
+    qkv = None if nxt is None else torch.empty(x_in.shape[0], x_in.shape[1], 1536, dtype=torch.bfloat16, device=dev)
+    scratch = None
+    if lay is not None:
+        scratch = _chain_scratch.get(dev)
+        if scratch is None:
+            scratch = _chain_scratch[dev] = torch.empty(A.lib.case_encoder_chain_scratch_bytes() // 2, dtype=torch.bfloat16, device=dev)
+    x_in = x_in if x_in.is_contiguous() else x_in.contiguous()
+    if resid is not None and not resid.is_contiguous():
+        resid = resid.contiguous()
+    A.call("case_encoder_chain", d, _ptr(x_in), _ptr(resid), _ptr(packed),
+           _ptr(None if lay is None else f32(lay.self_attn.out_proj.bias)), _ptr(None if lay is None else f32(lay.linear1.bias)),
+           _ptr(None if lay is None else f32(lay.linear2.bias)), _ptr(None if nxt is None else f32(nxt.self_attn.in_proj_bias)),
+           _ptr(None if lay is None else f32(lay.norm2.weight)), _ptr(None if lay is None else f32(lay.norm2.bias)),
+           _ptr(None if nxt is None else f32(nxt.norm1.weight)), _ptr(None if nxt is None else f32(nxt.norm1.bias)),
+           _ptr(s_out), _ptr(qkv), _ptr(scratch), _stream())
+    return s_out, qkv
 
 
 # ----------------------------------------------------------------------------------------------

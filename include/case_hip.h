@@ -335,6 +335,31 @@ int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t 
 int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
                         double beta1, double beta2, double eps, double ema_w, case_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K16  the row-local half of an encoder layer in ONE launch (inference form, bf16, d_model = dim_feedforward = 512):
+ *   common/TransformerEncoder.py:66-75 around the attention core, and the next layer's :66-67:
+ *     y = x_in Wo^T + bo + resid;  s2 = LN2(y);  o = gelu(s2 W1^T + b1) W2^T + b2 + s2;  s' = LN1_next(o);  qkv' = s' Wqkv'^T + bqkv'
+ *   variant 0 (full):  x_in = this layer's attention output [rows, 512], resid = its normed input s; writes s_out = s', qkv_out = qkv'
+ *   variant 1 (tail):  the last layer: writes s_out = o (the encoder output); LN1_next / QKV arguments may be null
+ *   variant 2 (head):  layer 0: x_in = embedding output; writes s_out = LN1(x_in), qkv_out; the layer-stage arguments may be null
+ * Weights are passed PRE-PACKED (case_encoder_chain_pack: bf16 row-major [512, 512] x 3 and [1536, 512] -> MFMA fragment order,
+ * case_encoder_chain_packed_bytes() bytes; any matrix may be null for the variants that do not read it); biases and LayerNorm
+ * parameters f32.  scratch: case_encoder_chain_scratch_bytes() bytes (variants 0 / 1).  Of the 20 activation passes over HBM that
+ * the same chain makes as single GEMM / LayerNorm launches, 6 remain (x_in, resid in; s', qkv' out).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t rows;   /* tokens (sequences x length) */
+  int32_t width;  /* 512 */
+  int32_t variant;
+  float eps_ln2, eps_ln1_next;
+} CaseEncoderChainDesc;
+int64_t case_encoder_chain_packed_bytes(void);
+int64_t case_encoder_chain_scratch_bytes(void);
+int case_encoder_chain_pack(const void* wo, const void* w1, const void* w2, const void* wqkv, void* packed, case_stream_t stream);
+int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_in, const void* resid, const void* packed, const float* bo,
+                       const float* b1, const float* b2, const float* bqkv, const float* ln2_g, const float* ln2_b,
+                       const float* ln1n_g, const float* ln1n_b, void* s_out, void* qkv_out, void* scratch, case_stream_t stream);
+
 /* Greedy post-processing on the device (common/Utils.py:200-217 to_sentence): per row of ids [B, T] drop the BOS / PAD ids and
  * everything from the first EOS on; out [B, T] holds the kept ids front-packed (pad behind), len [B] their count.  One host
  * copy of (out, len) replaces the reference's `.item()` per generated token.  Pass -1 for a special id the vocabulary lacks. */
