@@ -87,7 +87,7 @@ SIGNATURES = {
     "case_row_argmax": [ptr, ptr, ptr, i64, i64, i64, ptr],
     "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
     "case_encoder_chain_pack": [ptr, ptr, ptr, ptr, ptr, ptr],
-    "case_encoder_chain": [C.POINTER(EncoderChainDesc)] + [ptr] * 15,
+    "case_encoder_chain": [C.POINTER(EncoderChainDesc)] + [ptr] * 14,
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
     "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
 }
@@ -105,9 +105,8 @@ def _load():
         fn.restype = C.c_int
     lib.case_optim_chunk_elems.restype = C.c_int
     lib.case_optim_chunk_elems.argtypes = []
-    for fn in (lib.case_encoder_chain_packed_bytes, lib.case_encoder_chain_scratch_bytes):
-        fn.restype = C.c_int64
-        fn.argtypes = []
+    lib.case_encoder_chain_packed_bytes.restype = C.c_int64
+    lib.case_encoder_chain_packed_bytes.argtypes = []
     lib.case_version.restype = C.c_int
     lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()
     lib.case_gemm_tile_for.argtypes = [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr]

@@ -13,20 +13,22 @@
 // this layer are HBM-co-bound when launched one by one: what the chain removes is their traffic, not their FLOPs.
 //
 // Structure (d_model = dim_feedforward = 512, bf16):
-//   * workgroup = FOUR waves, one per SIMD, the whole 512-register file each (__launch_bounds__(256));
+//   * workgroup = EIGHT waves (two per SIMD: one wave's fragment loads and waits hide under its partner's MFMAs, and the VALU
+//     epilogues of two waves share a SIMD at full rate -- a wave alone on its SIMD issues vector instructions at half of it);
 //   * the activation tile X [128 tokens][512] lives in LDS (128 KiB, 16-byte chunks XOR-swizzled by the token's low four bits:
 //     every fragment read is conflict free) and is rewritten IN PLACE by each stage's epilogue;
 //   * the weights do not pass through LDS at all: they are pre-packed (case_encoder_chain_pack, once per parameter update) into
 //     MFMA fragment order -- one contiguous KiB per (16 features x 32 k) fragment, laid out in exactly the order a wave consumes
-//     them -- and each wave streams its share straight from L2 into registers, three K steps ahead of the MFMAs that use them
-//     (every CU reads the same 3 MB per layer: L2-resident);
-//   * a wave owns 128 of each GEMM's 512 output features, in two 64-feature passes (128 accumulator registers): per K step of
-//     32 it issues 4 weight-fragment loads, 8 token-fragment ds_read_b128 and 32 v_mfma_f32_16x16x32_bf16 with the FEATURES on
-//     the MFMA rows, so a lane's accumulators hold four consecutive features of ONE token: bias / residual / GELU / LayerNorm /
-//     packing to bf16 all happen in registers, and the packed result is the next GEMM's operand image once written back to X;
-//   * LayerNorm statistics: per-lane partial sums, two cross-lane adds, one 4 KiB exchange through LDS;
-//   * s2 (needed again as the residual behind FFN2) is parked in a per-workgroup global scratch slab in the lanes' own order
-//     (512-byte contiguous stores, read back by the same lanes: it never leaves L2 / the Infinity Cache).
+//     them -- and each wave streams its share straight from L2 into registers one K step ahead of the MFMAs that use them
+//     (every CU reads the same 3 MB per layer: L2-resident; a 64-token tile would double that stream and saturate the CU's
+//     64 B/clk vector-memory path, which is why the tile is 128 tokens);
+//   * a wave owns 64 of each stage's 512 output features for all 128 tokens (128 accumulator registers): per K step of 32 it
+//     issues 4 weight-fragment loads, 8 token-fragment ds_read_b128 and 32 v_mfma_f32_16x16x32_bf16 with the FEATURES on the
+//     MFMA rows, so a lane's accumulators hold four consecutive features of ONE token: bias / residual / GELU / LayerNorm /
+//     packing to bf16 happen in registers, and the packed result is the next stage's operand image once written back to X;
+//   * a wave owns the same feature columns in the accumulators and in X, so the FFN2 residual never leaves the CU: in the FFN1
+//     epilogue each lane reads the 8 bytes of s2 it is about to overwrite with gelu(.) and seeds its FFN2 accumulators with them;
+//   * LayerNorm statistics: per-lane partial sums over the f32 accumulators, two cross-lane adds, one 8 KiB exchange through LDS.
 // Variants: HEAD (layer 0: x -> LN1 -> s, qkv), FULL (layer i -> i + 1), TAIL (last layer: o is the encoder output).
 #include "common.h"
 
@@ -38,12 +40,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-constexpr int E = 512, TOK = 128, NTHR = 256, NWAVE = 4, KSTEPS = E / 32;
+constexpr int E = 512, TOK = 128, NTHR = 512, NWAVE = 8, KSTEPS = E / 32;
 constexpr int XBYTES = TOK * E * 2;              // 128 KiB activation tile
 constexpr int STAT_BYTES = TOK * NWAVE * 8;      // [token][wave] (sum, sum of squares)
-constexpr int LDS_BYTES = XBYTES + STAT_BYTES;
-constexpr int SLOTS = 12;                        // per wave: 2 x Wo, 2 x W1, 2 x W2, 6 x Wqkv sub-chunks of 64 features
-constexpr int STEP_BYTES = 4 * 1024;             // one K step of one sub-chunk: 4 fragments of 1 KiB
+// biases and LayerNorm parameters of the layer, staged once per workgroup (the epilogues read them with ds_read: a global load there
+// is a full L2 round trip that nothing hides, and it queues behind the weight prefetch in vmcnt order)
+enum { P_BO = 0, P_B1 = 512, P_B2 = 1024, P_G2 = 1536, P_BE2 = 2048, P_G1N = 2560, P_BE1N = 3072, P_BQKV = 3584, P_FLOATS = 5120 };
+constexpr int LDS_BYTES = XBYTES + STAT_BYTES + P_FLOATS * 4;  // 159,744 of the CU's 163,840 bytes
+constexpr int SLOTS = 6;                         // per wave: Wo, W1, W2, Wq, Wk, Wv sub-blocks of 64 output features
+constexpr int STEP_BYTES = 4 * 1024;             // one K step: 4 fragments of 1 KiB
 constexpr int SLOT_BYTES = KSTEPS * STEP_BYTES;  // 64 KiB
 constexpr int64_t WAVE_BYTES = (int64_t)SLOTS * SLOT_BYTES, PACKED_BYTES = NWAVE * WAVE_BYTES;  // 3 MiB per layer
 
@@ -56,30 +61,22 @@ struct Args {
   const float *bo, *b1, *b2, *bqkv, *g2, *be2, *g1n, *be1n;
   bf16_t* s_out;         // FULL / HEAD: s' [M, 512]; TAIL: the layer output o [M, 512]
   bf16_t* qkv_out;       // FULL / HEAD: [M, 1536]
-  bf16_t* scratch;       // FULL / TAIL: gridDim.x slabs of 128 x 512 bf16
   int64_t M;
   float eps2, eps1n;
 };
 
 // ---- weight packing -------------------------------------------------------------------------------------------------------------------------
 // packed[wave][slot][ks][nb][lane][8]: lane l of fragment (nb, ks) holds W[n0 + 16 nb + (l & 15)][32 ks + 8 (l >> 4) + 0..7], the A operand
-// of v_mfma_f32_16x16x32_bf16 with the features on the rows.  slot -> (matrix, first feature n0): 0-1 Wo, 2-3 W1, 4-5 W2 at
-// n0 = 64 (2 wave + (slot & 1)); 6 + 2 c + i: Wqkv at 512 c + 64 (2 wave + i).
+// of v_mfma_f32_16x16x32_bf16 with the features on the rows.  slot -> (matrix, first feature n0): 0 Wo, 1 W1, 2 W2 at n0 = 64 wave;
+// 3 + c: Wqkv at 512 c + 64 wave.
 __global__ __launch_bounds__(256) void pack_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
                                                    const bf16_t* __restrict__ wqkv, u32x4* __restrict__ out) {
   const int64_t frag = blockIdx.x * 4 + (threadIdx.x >> 6);  // fragment index: ((wave * SLOTS + slot) * KSTEPS + ks) * 4 + nb
   const int l = threadIdx.x & 63;
   const int nb = (int)(frag & 3), ks = (int)((frag >> 2) % KSTEPS), slot = (int)((frag / (4 * KSTEPS)) % SLOTS),
             wave = (int)(frag / (4 * KSTEPS * SLOTS));
-  const bf16_t* src;
-  int n0;
-  if (slot < 6) {
-    src = slot < 2 ? wo : (slot < 4 ? w1 : w2);
-    n0 = 64 * (2 * wave + (slot & 1));
-  } else {
-    src = wqkv;
-    n0 = 512 * ((slot - 6) >> 1) + 64 * (2 * wave + (slot & 1));
-  }
+  const bf16_t* src = slot == 0 ? wo : (slot == 1 ? w1 : (slot == 2 ? w2 : wqkv));
+  const int n0 = (slot < 3 ? 0 : 512 * (slot - 3)) + 64 * wave;
   u32x4 v = {0u, 0u, 0u, 0u};
   if (src) v = *reinterpret_cast<const u32x4*>(src + (int64_t)(n0 + 16 * nb + (l & 15)) * E + 32 * ks + 8 * (l >> 4));
   out[frag * 64 + l] = v;
@@ -108,8 +105,42 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned lds_ad
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// 4 x 4 transpose across the four 16-lane rows of a wave (two v_permlane32_swap + two v_permlane16_swap): register i of lane row j
+// <-> register j of lane row i.  In the accumulator layout lane row g holds, per 16-feature block nb, the 4 features 16 nb + 4 g ..;
+// transposed, lane row g holds the 16 CONSECUTIVE features 16 g .. 16 g + 15 of the wave's 64: 32 contiguous bytes per lane, so
+// global and LDS accesses are 16-byte vectors that cover whole 128-byte lines between the four lanes of a token (an 8-byte
+// store per lane touches 16 lines per instruction with a quarter of each: the QKV stores alone cost a third of the kernel that way).
+__device__ __forceinline__ void tr4(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3) {
+  const auto a = __builtin_amdgcn_permlane32_swap(r0, r2, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(r1, r3, false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  r0 = c[0]; r1 = c[1]; r2 = d[0]; r3 = d[1];
+}
+// the wave's 64 features of one token block, packed bf16 pairs lo[nb] (features +0, +1) / hi[nb] (+2, +3) in accumulator layout ->
+// two 16-byte vectors per lane: features 16 lg .. + 7 and 16 lg + 8 .. + 15
+__device__ __forceinline__ void to_rows(uint32_t (&lo)[4], uint32_t (&hi)[4], u32x4& v0, u32x4& v1) {
+  tr4(lo[0], lo[1], lo[2], lo[3]);
+  tr4(hi[0], hi[1], hi[2], hi[3]);
+  v0 = u32x4{lo[0], hi[0], lo[1], hi[1]};
+  v1 = u32x4{lo[2], hi[2], lo[3], hi[3]};
+}
+
 // physical byte offset of 16-byte chunk c (0..63) of token row r in the X image
 __device__ __forceinline__ int x_off(int r, int c) { return r * 1024 + ((c ^ (r & 15)) << 4); }
+
+#ifdef CHAIN_STAMPS
+// diagnostic build only: s_memtime at the phase boundaries of each workgroup's SECOND tile, wave STAMP_WAVE, into a device array that
+// case_encoder_chain_stamps() copies out (tools/chain_stamps.py); no output value depends on it
+__device__ uint64_t g_stamps[256 * 32];
+#define EC_STAMP(i) { if (wave == STAMP_WAVE && tile == (int)(blockIdx.x + gridDim.x)) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+    if (l == 0) g_stamps[(int)blockIdx.x * 32 + (i)] = t_; } }
+#else
+#define EC_STAMP(i)
+#endif
+#ifndef STAMP_WAVE
+#define STAMP_WAVE 0
+#endif
 
 template <int VARIANT>
 __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
@@ -118,36 +149,70 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
   const int lt = l & 15, lg = l >> 4;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   float* stats = reinterpret_cast<float*>(smem + XBYTES);
-
-  constexpr int FIRST_SLOT = VARIANT == VAR_HEAD ? 6 : 0, LAST_SLOT = VARIANT == VAR_TAIL ? 6 : 12;
-  constexpr int NSTEP = (LAST_SLOT - FIRST_SLOT) * KSTEPS;  // K steps per tile of this wave's weight stream
-  const int ntiles = (int)((g.M + TOK - 1) / TOK);
-
-  // the wave's weight stream: step s (0 .. NSTEP-1, then it wraps for the next tile) = 4 fragments at wbase + s * STEP_BYTES
-  const __amdgpu_buffer_rsrc_t wr = as_rsrc(reinterpret_cast<const char*>(g.wpk) + wave * WAVE_BYTES + (int64_t)FIRST_SLOT * SLOT_BYTES,
-                                            (uint32_t)(NSTEP * STEP_BYTES));
-  const int wv = l * 16;
-  u32x4 wring[4][4];  // K steps in flight: ring of 4, prefetch distance 3
-  int wstep = 0;      // stream position of the NEXT step to request
-  auto request = [&](u32x4 (&dst)[4]) {
-    const int so = wstep * STEP_BYTES;
+  float* par = reinterpret_cast<float*>(smem + XBYTES + STAT_BYTES);
+  {
+    const float* src[8] = {g.bo, g.b1, g.b2, g.g2, g.be2, g.g1n, g.be1n, g.bqkv};
+    const int off[8] = {P_BO, P_B1, P_B2, P_G2, P_BE2, P_G1N, P_BE1N, P_BQKV};
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) dst[nb] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + nb * 1024, so, 0);
-    wstep = wstep + 1 == NSTEP ? 0 : wstep + 1;
-  };
-  request(wring[0]);
-  request(wring[1]);
-  request(wring[2]);
+    for (int i = 0; i < 8; ++i) {
+      const int n = i == 7 ? 1536 : 512;
+      if (src[i])
+        for (int k = tid; k < n; k += NTHR) par[off[i] + k] = src[i][k];
+    }
+    // visible to every wave behind the first tile's barrier
+  }
 
-  // per-lane parts of the global addresses (the uniform parts ride in the scalar offset) and of the X fragment addresses
-  const int v_row = (lt * E + 4 * lg) * 2, v_row3 = (lt * 3 * E + 4 * lg) * 2;
+  constexpr int ST0 = VARIANT == VAR_HEAD ? 3 : 0, ST1 = VARIANT == VAR_TAIL ? 3 : 6;  // stages: 0 out-proj, 1 FFN1, 2 FFN2, 3..5 Q / K / V
+  constexpr int NSTEP = (ST1 - ST0) * KSTEPS;  // K steps per tile of this wave's weight stream
+  const int ntiles = (int)((g.M + TOK - 1) / TOK);
+  const int n0 = 64 * wave;  // the wave's feature columns inside every stage's 512-wide output
+
+  // the wave's weight stream: step s (0 .. NSTEP-1, wrapping for the next tile) = 4 fragments at s * STEP_BYTES
+  const __amdgpu_buffer_rsrc_t wr =
+      as_rsrc(reinterpret_cast<const char*>(g.wpk) + wave * WAVE_BYTES + (int64_t)ST0 * SLOT_BYTES, (uint32_t)(NSTEP * STEP_BYTES));
+  const int wv = l * 16;
+  int wstep = 0;  // stream position of the NEXT step to request
+  u32x4 wa[4], wb[4];  // weight fragments of two consecutive K steps; a request runs one step ahead of its use
+#define EC_REQUEST(dst)                                                                                   \
+  {                                                                                                       \
+    const int so_ = wstep * STEP_BYTES;                                                                   \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) dst[nb] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + nb * 1024, so_, 0); \
+    wstep = wstep + 1 == NSTEP ? 0 : wstep + 1;                                                           \
+  }
+  EC_REQUEST(wa)
+
+  // per-lane parts of the global addresses (the uniform parts ride in the scalar offset) and of the X addresses
+  const int v_row = (lt * E + n0 + 16 * lg) * 2, v_row3 = (lt * 3 * E + n0 + 16 * lg) * 2;  // row-layout accesses: 32 bytes per lane
+  // fragment read: chunk 4 ks + lg of row 16 tb + lt  ->  xlane + ((ks ^ (lt >> 2)) << 6) + tb * 16384
   const int xlane = lt * 1024 + ((lg ^ (lt & 3)) << 4);
+  // epilogue write: features n0 + 16 nb + 4 lg .. + 3 of row 16 tb + lt -> chunk 8 wave + 2 nb + (lg >> 1), half lg & 1
+  //   -> xw + (((2 nb) ^ xq) << 4) + tb * 16384,   xq = lt ^ (lg >> 1) ^ (8 (wave & 1)),   xw = lt * 1024 + (wave >> 1) * 256 + (lg & 1) * 8
+  const int xq = lt ^ (lg >> 1) ^ (8 * (wave & 1)), xw = lt * 1024 + (wave >> 1) * 256 + (lg & 1) * 8;
+  // row-layout write (after to_rows): features n0 + 16 lg .. + 15 = chunks 8 wave + 2 lg and + 1 -> xr + ((xq2) << 4), xr + ((xq2 ^ 1) << 4)
+  const int xq2 = lt ^ (8 * (wave & 1) + 2 * lg), xr = lt * 1024 + (wave >> 1) * 256;
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = (int64_t)tile * TOK;
     const int rows = (int)(g.M - row0 < TOK ? g.M - row0 : TOK);
     const uint32_t tile_bytes_e = (uint32_t)rows * E * 2;
+    const __amdgpu_buffer_rsrc_t rso = as_rsrc(g.s_out + row0 * E, tile_bytes_e);
+    const __amdgpu_buffer_rsrc_t rqkv = as_rsrc(g.qkv_out ? g.qkv_out + row0 * (3 * E) : nullptr, g.qkv_out ? (uint32_t)rows * 3 * E * 2 : 0);
 
-    // ---- stage 0: the input tile -> X (LDS-DMA, one 1 KiB row per wave-instruction, chunks permuted on the SOURCE side) -------------
+    EC_STAMP(0)
+    f32x4 acc[8][4];
+    // ---- stage 0 accumulators: bo + s (requested now, in flight under the tile DMA) -----------------------------------------
+    // (row layout: 32 contiguous bytes per lane; two halves of four token blocks keep the registers in flight at 32)
+    u32x4 rr[4][2];
+    __amdgpu_buffer_rsrc_t rres = rso;
+    if constexpr (VARIANT != VAR_HEAD) {
+      rres = as_rsrc(g.resid + row0 * E, tile_bytes_e);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        rr[tb][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row, tb * 16 * E * 2, 0);
+        rr[tb][1] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row, tb * 16 * E * 2 + 16, 0);
+      }
+    }
+    // ---- the input tile -> X (LDS-DMA, one 1 KiB row per wave-instruction, chunks permuted on the SOURCE side) -----------------
     {
       const i32x4 rs = make_rsrc(g.ctx + row0 * E, tile_bytes_e);
 #pragma unroll 4
@@ -155,13 +220,41 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
         const int r = wave * (TOK / NWAVE) + i;
         dma16(rs, (unsigned)(r * 1024 + ((l ^ (r & 15)) << 4)), lds0 + r * 1024);
       }
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's rows have landed
-      __syncthreads();
     }
+    if constexpr (VARIANT != VAR_HEAD) {
+      f32x4 b4[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(g.bo + n0 + 16 * nb + 4 * lg);  // first tile: LDS copy not yet visible
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int tb = half * 4 + t4;
+          // row layout -> accumulator layout: the same 4 x 4 lane-row transpose
+          uint32_t lo[4] = {rr[t4][0][0], rr[t4][0][2], rr[t4][1][0], rr[t4][1][2]}, hi[4] = {rr[t4][0][1], rr[t4][0][3], rr[t4][1][1], rr[t4][1][3]};
+          if (half == 0) {  // the second half's rows are requested as the first half's registers come free
+            rr[t4][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row, (tb + 4) * 16 * E * 2, 0);
+            rr[t4][1] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row, (tb + 4) * 16 * E * 2 + 16, 0);
+          }
+          tr4(lo[0], lo[1], lo[2], lo[3]);
+          tr4(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            acc[tb][nb][0] = b4[nb][0] + bf_lo(lo[nb]);
+            acc[tb][nb][1] = b4[nb][1] + bf_hi(lo[nb]);
+            acc[tb][nb][2] = b4[nb][2] + bf_lo(hi[nb]);
+            acc[tb][nb][3] = b4[nb][3] + bf_hi(hi[nb]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's rows have landed
+    EC_STAMP(1)
+    __syncthreads();
+    EC_STAMP(2)
 
-    // LayerNorm of the tile's rows IN LDS (HEAD: x -> s): a wave normalises 32 rows, 8 elements per lane per row
+    // LayerNorm of the tile's rows IN LDS (HEAD: x -> s): a wave normalises 16 rows, 8 elements per lane per row, two rows at a time
     if constexpr (VARIANT == VAR_HEAD) {
-      const __amdgpu_buffer_rsrc_t so = as_rsrc(g.s_out + row0 * E, tile_bytes_e);
       float gam[8], bet[8];
 #pragma unroll
       for (int e = 0; e < 8; e += 4) {
@@ -169,187 +262,192 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { gam[e + i] = a[i]; bet[e + i] = b[i]; }
       }
-      for (int i = 0; i < TOK / NWAVE; ++i) {
-        const int r = wave * (TOK / NWAVE) + i;
-        u32x4* p = reinterpret_cast<u32x4*>(smem + x_off(r, l));
-        const u32x4 w = *p;
-        float x[8];
+      for (int i = 0; i < TOK / NWAVE; i += 2) {
+        float x[2][8], s1[2], s2[2];
+        u32x4* p[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { x[2 * k] = bf_lo(w[k]); x[2 * k + 1] = bf_hi(w[k]); }
-        float s1 = 0.f;
+        for (int u = 0; u < 2; ++u) {
+          const int r = wave * (TOK / NWAVE) + i + u;
+          p[u] = reinterpret_cast<u32x4*>(smem + x_off(r, l));
+          const u32x4 w = *p[u];
+          s1[u] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s1 += x[k];
-        const float mean = wave_sum(s1) * (1.f / E);
-        float s2 = 0.f;
+          for (int k = 0; k < 4; ++k) { x[u][2 * k] = bf_lo(w[k]); x[u][2 * k + 1] = bf_hi(w[k]); }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { x[k] -= mean; s2 += x[k] * x[k]; }
-        const float rstd = rsqrtf(wave_sum(s2) * (1.f / E) + g.eps1n);
-        u32x4 o;
+          for (int k = 0; k < 8; ++k) s1[u] += x[u][k];
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          o[k] = f32x2_to_bf16x2(x[2 * k] * rstd * gam[2 * k] + bet[2 * k], x[2 * k + 1] * rstd * gam[2 * k + 1] + bet[2 * k + 1]);
-        *p = o;
-        __builtin_amdgcn_raw_buffer_store_b128(o, so, r * 1024 + l * 16, 0, 0);  // rows beyond M fall outside the descriptor
+        for (int o = 32; o > 0; o >>= 1) { s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float mean = s1[u] * (1.f / E);
+          s2[u] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { x[u][k] -= mean; s2[u] += x[u][k] * x[u][k]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s2[0] += __shfl_xor(s2[0], o, 64); s2[1] += __shfl_xor(s2[1], o, 64); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = wave * (TOK / NWAVE) + i + u;
+          const float rstd = rsqrtf(s2[u] * (1.f / E) + g.eps1n);
+          u32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = f32x2_to_bf16x2(x[u][2 * k] * rstd * gam[2 * k] + bet[2 * k], x[u][2 * k + 1] * rstd * gam[2 * k + 1] + bet[2 * k + 1]);
+          *p[u] = o;
+          __builtin_amdgcn_raw_buffer_store_b128(o, rso, r * 1024 + l * 16, 0, 0);  // rows beyond M fall outside the descriptor
+        }
       }
       __syncthreads();
     }
 
-    uint32_t hold[2][8][4][2];  // the wave's packed outputs of a stage (2 sub-chunks x 8 token blocks x 4 feature blocks x 4 bf16)
-    float ps1[8], ps2[8];       // LayerNorm partial sums per token block (this lane's features)
-
-    const __amdgpu_buffer_rsrc_t rres = as_rsrc(g.resid ? g.resid + row0 * E : nullptr, g.resid ? tile_bytes_e : 0);
-    const __amdgpu_buffer_rsrc_t rscr = as_rsrc(g.scratch ? g.scratch + (int64_t)blockIdx.x * TOK * E : nullptr, g.scratch ? XBYTES : 0);
-    const __amdgpu_buffer_rsrc_t rso = as_rsrc(g.s_out + row0 * E, tile_bytes_e);
-    const __amdgpu_buffer_rsrc_t rqkv = as_rsrc(g.qkv_out ? g.qkv_out + row0 * (3 * E) : nullptr, g.qkv_out ? (uint32_t)rows * 3 * E * 2 : 0);
-
-    // stages: 0 out-proj, 1 FFN1, 2 FFN2, 3..5 QKV chunks
-    constexpr int ST0 = VARIANT == VAR_HEAD ? 3 : 0, ST1 = VARIANT == VAR_TAIL ? 3 : 6;
     for (int st = ST0; st < ST1; ++st) {
-      if (st == 0 || st == 2) {
+      if (st == 1 || st >= 3) {  // no residual in front of the GEMM: the bias is added in the epilogue
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) ps1[tb] = ps2[tb] = 0.f;
+        for (int tb = 0; tb < 8; ++tb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[tb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        // feature origin of this sub-chunk inside its stage's 512-wide output, and the per-lane feature offset
-        const int n0 = 64 * (2 * wave + j);
-        const float* bias = st == 0 ? g.bo : (st == 1 ? g.b1 : (st == 2 ? g.b2 : g.bqkv + 512 * (st - 3)));
-        f32x4 acc[8][4];
-        // ---- accumulator init: bias (+ residual) ---------------------------------------------------------------------------
+      // ---- K loop: 16 steps of 32; weights one step ahead (wa / wb alternate), token fragments refilled behind their MFMAs ---------
+      {
+        int xl = xlane, xh = lt >> 2;
+        asm volatile("" : "+v"(xl), "+v"(xh));  // opaque: the per-step addresses are recomputed, not hoisted out of the tile loop
+        bf16x8 xf[8];
         {
-          f32x4 b4[4];
+          const char* p0 = smem + xl + ((0 ^ xh) << 6);
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bias + n0 + 16 * nb + 4 * lg);
-          if (st == 0 || st == 2) {
-            u32x2 rr[8][4];
-            if (st == 0) {  // s, row-major [M, 512]: 4 consecutive features of token 16 tb + lt
-#pragma unroll
-              for (int tb = 0; tb < 8; ++tb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                  rr[tb][nb] = __builtin_amdgcn_raw_buffer_load_b64(rres, v_row, tb * 16 * E * 2 + (n0 + 16 * nb) * 2, 0);
-            } else {  // s2 from the scratch slab, lane order
-#pragma unroll
-              for (int tb = 0; tb < 8; ++tb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                  rr[tb][nb] = __builtin_amdgcn_raw_buffer_load_b64(rscr, l * 8, (((wave * 2 + j) * 8 + tb) * 4 + nb) * 512, 0);
-            }
-#pragma unroll
-            for (int tb = 0; tb < 8; ++tb)
-#pragma unroll
-              for (int nb = 0; nb < 4; ++nb) {
-                acc[tb][nb][0] = b4[nb][0] + bf_lo(rr[tb][nb][0]);
-                acc[tb][nb][1] = b4[nb][1] + bf_hi(rr[tb][nb][0]);
-                acc[tb][nb][2] = b4[nb][2] + bf_lo(rr[tb][nb][1]);
-                acc[tb][nb][3] = b4[nb][3] + bf_hi(rr[tb][nb][1]);
-              }
-          } else {
-#pragma unroll
-            for (int tb = 0; tb < 8; ++tb)
-#pragma unroll
-              for (int nb = 0; nb < 4; ++nb) acc[tb][nb] = b4[nb];
-          }
+          for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(p0 + tb * 16384);
         }
-        // ---- K loop: 16 steps of 32 -----------------------------------------------------------------------------------------
-        // X fragment of token block tb, K step ks: chunk 4 ks + lg of row 16 tb + lt, i.e. byte
-        //   lt * 1024 + tb * 16384 + ((((4 ks + lg) ^ lt)) << 4) = xlane + ((ks ^ (lt >> 2)) << 6) + tb * 16384,   xlane = lt * 1024 + ((lg ^ (lt & 3)) << 4)
-        // One fragment buffer: fragment tb of the NEXT step is requested right behind the four MFMAs that consumed fragment tb of
-        // this one (28 MFMAs = 450 cycles cover the LDS latency).
-        {
-          int xl = xlane, xh = lt >> 2;
-          asm volatile("" : "+v"(xl), "+v"(xh));  // opaque: keeps the 16 per-step addresses from being hoisted out of the tile loop (and spilled)
-          bf16x8 xf[8];
-          {
-            const char* p0 = smem + xl + ((0 ^ xh) << 6);
-#pragma unroll
-            for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(p0 + tb * 16384);
-          }
-#pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks) {
-#ifndef CHAIN_DBG_NO_WLOAD
-            request(wring[(ks + 3) & 3]);
-#endif
-            const char* pn = smem + xl + ((((ks + 1) & (KSTEPS - 1)) ^ xh) << 6);
-#pragma unroll
-            for (int tb = 0; tb < 8; ++tb) {
-#pragma unroll
-              for (int nb = 0; nb < 4; ++nb)
-                acc[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wring[ks & 3][nb]), xf[tb], acc[tb][nb], 0, 0, 0);
 #ifndef CHAIN_DBG_NO_XREAD
-              if (ks + 1 < KSTEPS) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);
+#define EC_REFILL xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);
+#else
+#define EC_REFILL
 #endif
-              __builtin_amdgcn_sched_barrier(0);  // keep the refill behind its MFMAs and each step's requests inside the step
-            }
+#define EC_STEP(W, KS)                                                                                                              \
+  {                                                                                                                                  \
+    const char* pn = smem + xl + (((((KS) + 1) & (KSTEPS - 1)) ^ xh) << 6);                                                          \
+    _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) {                                                                               \
+      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                               \
+        acc[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&W[nb]), xf[tb], acc[tb][nb], 0, 0, 0); \
+      EC_REFILL                                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    }                                                                                                                                \
+  }
+        // Past the stage's last step the request is the next stage's (or the next tile's) first step: the stream is continuous.
+        for (int ks = 0; ks < KSTEPS; ks += 2) {
+#ifndef CHAIN_DBG_NO_WLOAD
+          EC_REQUEST(wb)
+#endif
+          EC_STEP(wa, ks)
+#ifndef CHAIN_DBG_NO_WLOAD
+          EC_REQUEST(wa)
+#endif
+          EC_STEP(wb, ks + 1)
+        }
+#undef EC_STEP
+      }
+      EC_STAMP(3 + 4 * st)
+
+      // ---- epilogues ---------------------------------------------------------------------------------------------------------------
+      if (st >= 3) {  // Q / K / V: + bias, pack, lane-row transpose, store [M, 1536] as 16-byte vectors
+        const float* bias = par + P_BQKV + 512 * (st - 3) + n0 + 4 * lg;
+        f32x4 b4[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bias + 16 * nb);
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+          uint32_t lo[4], hi[4];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            lo[nb] = f32x2_to_bf16x2(acc[tb][nb][0] + b4[nb][0], acc[tb][nb][1] + b4[nb][1]);
+            hi[nb] = f32x2_to_bf16x2(acc[tb][nb][2] + b4[nb][2], acc[tb][nb][3] + b4[nb][3]);
+          }
+          u32x4 v0, v1;
+          to_rows(lo, hi, v0, v1);
+#ifndef CHAIN_DBG_NO_QSTORE
+          // The whole offset rides in the per-lane register, the scalar offset stays the immediate 0: a 16-byte buffer store whose
+          // soffset is an SGPR reads its data registers over several cycles and hipcc (ROCm 7.2) only guards the immediate form --
+          // VALU writes scheduled right behind the store then reach the last lanes of each half (seen here as wrong / NaN values
+          // in lanes 28-31 / 60-63 of single token blocks, timing dependent); the same hazard as in gemm8w.inc's drain_pass.
+          const int vo = v_row3 + tb * 16 * 3 * E * 2 + 512 * (st - 3) * 2;
+          __builtin_amdgcn_raw_buffer_store_b128(v0, rqkv, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v1, rqkv, vo + 16, 0, 0);
+#endif
+        }
+        EC_STAMP(6 + 4 * st)
+        continue;  // X is unchanged: the next stage's K loop may start at once (the waves drift apart here, on purpose)
+      }
+      if (st == 1) {
+        // FFN1: a = gelu(acc + b1) goes into X where s2 stood; the s2 this lane overwrites seeds its FFN2 accumulators (b2 + s2)
+        __syncthreads();  // every wave is behind its K loop: nobody reads X any more
+        EC_STAMP(4 + 4 * st)
+        int q = xq, wbase = xw;
+        asm volatile("" : "+v"(q), "+v"(wbase));
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(par + P_B1 + n0 + 16 * nb + 4 * lg);
+          const f32x4 b2v = *reinterpret_cast<const f32x4*>(par + P_B2 + n0 + 16 * nb + 4 * lg);
+          char* px = smem + wbase + (((2 * nb) ^ q) << 4);
+#pragma unroll
+          for (int tb = 0; tb < 8; ++tb) {
+            u32x2* p = reinterpret_cast<u32x2*>(px + tb * 16384);
+            const u32x2 old = *p;
+            u32x2 w;
+            w[0] = f32x2_to_bf16x2(gelu_f(acc[tb][nb][0] + b1v[0]), gelu_f(acc[tb][nb][1] + b1v[1]));
+            w[1] = f32x2_to_bf16x2(gelu_f(acc[tb][nb][2] + b1v[2]), gelu_f(acc[tb][nb][3] + b1v[3]));
+            *p = w;
+            acc[tb][nb][0] = b2v[0] + bf_lo(old[0]);
+            acc[tb][nb][1] = b2v[1] + bf_hi(old[0]);
+            acc[tb][nb][2] = b2v[2] + bf_lo(old[1]);
+            acc[tb][nb][3] = b2v[3] + bf_hi(old[1]);
           }
         }
-        // ---- per-sub-chunk epilogue ------------------------------------------------------------------------------------------
-        if (st >= 3) {  // QKV: bias is in, pack and store [M, 1536]
-          const int col = 512 * (st - 3) + n0;
-#pragma unroll
-          for (int tb = 0; tb < 8; ++tb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-              u32x2 w;
-              w[0] = f32x2_to_bf16x2(acc[tb][nb][0], acc[tb][nb][1]);
-              w[1] = f32x2_to_bf16x2(acc[tb][nb][2], acc[tb][nb][3]);
-              __builtin_amdgcn_raw_buffer_store_b64(w, rqkv, v_row3, tb * 16 * 3 * E * 2 + (col + 16 * nb) * 2, 0);
-            }
-        } else {
-#pragma unroll
-          for (int tb = 0; tb < 8; ++tb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-              float v0 = acc[tb][nb][0], v1 = acc[tb][nb][1], v2 = acc[tb][nb][2], v3 = acc[tb][nb][3];
-              if (st == 1) { v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); }
-              const uint32_t w0 = f32x2_to_bf16x2(v0, v1), w1 = f32x2_to_bf16x2(v2, v3);
-              hold[j][tb][nb][0] = w0;
-              hold[j][tb][nb][1] = w1;
-              if (st != 1 && !(VARIANT == VAR_TAIL && st == 2)) {  // statistics of the ROUNDED values, as a LayerNorm pass over bf16 y sees them
-                const float r0 = bf_lo(w0), r1 = bf_hi(w0), r2 = bf_lo(w1), r3 = bf_hi(w1);
-                ps1[tb] += (r0 + r1) + (r2 + r3);
-                ps2[tb] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-              }
-            }
-        }
+        EC_STAMP(5 + 4 * st)
+        __syncthreads();  // X holds a
+        EC_STAMP(6 + 4 * st)
+        continue;
       }
-      if (st >= 3) continue;
-
-      // ---- stage epilogue: (LayerNorm), write the 128 x 128 block of this wave back into X ------------------------------------------
-      const bool do_ln = (st == 0) || (st == 2 && VARIANT != VAR_TAIL);
+      // st == 0 (y -> LN2 -> s2) or st == 2 (o -> LN1' -> s'; TAIL: o itself)
+      const bool do_ln = !(VARIANT == VAR_TAIL && st == 2);
       float mean[8], rstd[8];
       if (do_ln) {
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-          float a = ps1[tb], b = ps2[tb];
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a += acc[tb][nb][e]; b += acc[tb][nb][e] * acc[tb][nb][e]; }
           a += __shfl_xor(a, 16);
           b += __shfl_xor(b, 16);
           a += __shfl_xor(a, 32);
           b += __shfl_xor(b, 32);
-          if (lg == 0) *reinterpret_cast<float2*>(stats + ((tb * 16 + lt) * NWAVE + wave) * 2) = make_float2(a, b);
+          *reinterpret_cast<float2*>(stats + ((tb * 16 + lt) * NWAVE + wave) * 2) = make_float2(a, b);  // all four lane groups: same value
         }
       }
-      __syncthreads();  // every wave is behind its K loops: X is free; the partial sums are visible
+      __syncthreads();  // every wave is behind its K loop: X is free; the partial sums are visible
+      EC_STAMP(4 + 4 * st)
       if (do_ln) {
         const float eps = st == 0 ? g.eps2 : g.eps1n;
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-          const f32x4 p0 = *reinterpret_cast<const f32x4*>(stats + (tb * 16 + lt) * NWAVE * 2),
-                      p1 = *reinterpret_cast<const f32x4*>(stats + (tb * 16 + lt) * NWAVE * 2 + 4);
-          const float s1 = (p0[0] + p0[2]) + (p1[0] + p1[2]), s2 = (p0[1] + p0[3]) + (p1[1] + p1[3]);
+          const f32x4* ps = reinterpret_cast<const f32x4*>(stats + (tb * 16 + lt) * NWAVE * 2);
+          const f32x4 p0 = ps[0], p1 = ps[1], p2 = ps[2], p3 = ps[3];
+          const float s1 = ((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]));
+          const float s2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]));
           mean[tb] = s1 * (1.f / E);
           rstd[tb] = rsqrtf(fmaxf(s2 * (1.f / E) - mean[tb] * mean[tb], 0.f) + eps);
         }
       }
-      const float* gam = st == 0 ? g.g2 : g.g1n;
-      const float* bet = st == 0 ? g.be2 : g.be1n;
-      int xq = lt ^ (lg >> 1), xw = lt * 1024 + (lg & 1) * 8;
-      asm volatile("" : "+v"(xq), "+v"(xw));
+      {
+        const float* gam = par + (st == 0 ? P_G2 : P_G1N);
+        const float* bet = par + (st == 0 ? P_BE2 : P_BE1N);
+        int q2 = xq2, rbase = xr;
+        asm volatile("" : "+v"(q2), "+v"(rbase));
+        uint32_t pk[8][4][2];  // packed bf16 pairs: the accumulators die as they are packed (two registers for four)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n0 = 64 * (2 * wave + j);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < 4; ++nb) {  // pass 1, per feature block: gamma / beta of one block live at a time
           f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
           if (do_ln) {
             gm = *reinterpret_cast<const f32x4*>(gam + n0 + 16 * nb + 4 * lg);
@@ -357,29 +455,37 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
           }
 #pragma unroll
           for (int tb = 0; tb < 8; ++tb) {
-            uint32_t w0 = hold[j][tb][nb][0], w1 = hold[j][tb][nb][1];
-            if (do_ln) {
-              const float m = mean[tb], r = rstd[tb];
-              w0 = f32x2_to_bf16x2((bf_lo(w0) - m) * r * gm[0] + bt[0], (bf_hi(w0) - m) * r * gm[1] + bt[1]);
-              w1 = f32x2_to_bf16x2((bf_lo(w1) - m) * r * gm[2] + bt[2], (bf_hi(w1) - m) * r * gm[3] + bt[3]);
-            }
-            u32x2 w;
-            w[0] = w0;
-            w[1] = w1;
-            // X image: features n0 + 16 nb + 4 lg .. + 3 of token 16 tb + lt = half (lg & 1) of chunk (n0 + 16 nb) / 8 + (lg >> 1)
-            //   = xw + ((8 j + 2 nb) ^ xq) * 16 + tb * 16384 + wave * 256,   xq = lt ^ (lg >> 1),   xw = lt * 1024 + (lg & 1) * 8
-            *reinterpret_cast<u32x2*>(smem + xw + (((8 * j + 2 * nb) ^ xq) << 4) + tb * 16384 + wave * 256) = w;
-            if (st == 0)  // s2: parked for the FFN2 residual, lane order
-              __builtin_amdgcn_raw_buffer_store_b64(w, rscr, l * 8, (((wave * 2 + j) * 8 + tb) * 4 + nb) * 512, 0);
-            if (st == 2)  // s' (FULL) or the layer output (TAIL), row-major
-              __builtin_amdgcn_raw_buffer_store_b64(w, rso, v_row, tb * 16 * E * 2 + (n0 + 16 * nb) * 2, 0);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = do_ln ? ((acc[tb][nb][e] - mean[tb]) * rstd[tb]) * gm[e] + bt[e] : acc[tb][nb][e];
+            pk[tb][nb][0] = f32x2_to_bf16x2(v[0], v[1]);
+            pk[tb][nb][1] = f32x2_to_bf16x2(v[2], v[3]);
+          }
+        }
+        char* pa = smem + rbase + (q2 << 4);
+        char* pb = smem + rbase + ((q2 ^ 1) << 4);
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {  // pass 2, per token block: lane-row transpose, write X (and the global copy)
+          uint32_t lo[4] = {pk[tb][0][0], pk[tb][1][0], pk[tb][2][0], pk[tb][3][0]}, hi[4] = {pk[tb][0][1], pk[tb][1][1], pk[tb][2][1], pk[tb][3][1]};
+          u32x4 w0, w1;
+          to_rows(lo, hi, w0, w1);
+          *reinterpret_cast<u32x4*>(pa + tb * 16384) = w0;
+          *reinterpret_cast<u32x4*>(pb + tb * 16384) = w1;
+          if (st == 2) {  // s' (FULL) or the layer output (TAIL), row-major
+            const int vo = v_row + tb * 16 * E * 2;  // per-lane offset, immediate soffset 0: see the QKV stores
+            __builtin_amdgcn_raw_buffer_store_b128(w0, rso, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, rso, vo + 16, 0, 0);
           }
         }
       }
+      EC_STAMP(5 + 4 * st)
       __syncthreads();  // X holds the next stage's operand
+      EC_STAMP(6 + 4 * st)
     }
     __syncthreads();  // the last K loops are done before the next tile's DMA overwrites X
+    EC_STAMP(27)
   }
+#undef EC_REQUEST
 }
 
 template <int VARIANT>
@@ -396,7 +502,11 @@ int launch(const Args& a, int cus, hipStream_t s) {
 }  // namespace enc_chain
 
 extern "C" int64_t case_encoder_chain_packed_bytes(void) { return enc_chain::PACKED_BYTES; }
-extern "C" int64_t case_encoder_chain_scratch_bytes(void) { return (int64_t)256 * enc_chain::XBYTES; }
+#ifdef CHAIN_STAMPS
+extern "C" int case_encoder_chain_stamps(void* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(enc_chain::g_stamps), sizeof(uint64_t) * 256 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int case_encoder_chain_pack(const void* wo, const void* w1, const void* w2, const void* wqkv, void* packed, case_stream_t stream) {
   CASE_REQUIRE(packed, "case_encoder_chain_pack: null output");
@@ -411,16 +521,16 @@ extern "C" int case_encoder_chain_pack(const void* wo, const void* w1, const voi
 
 extern "C" int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_in, const void* resid, const void* packed, const float* bo,
                                   const float* b1, const float* b2, const float* bqkv, const float* ln2_g, const float* ln2_b,
-                                  const float* ln1n_g, const float* ln1n_b, void* s_out, void* qkv_out, void* scratch, case_stream_t stream) {
+                                  const float* ln1n_g, const float* ln1n_b, void* s_out, void* qkv_out, case_stream_t stream) {
   CASE_REQUIRE(d && x_in && packed && s_out, "case_encoder_chain: null argument");
   CASE_REQUIRE(d->width == enc_chain::E, "case_encoder_chain: built for d_model = dim_feedforward = 512 (got %d)", (int)d->width);
   CASE_REQUIRE(d->rows > 0 && d->rows < (1ll << 31) - 128, "case_encoder_chain: bad row count");
   CASE_REQUIRE(d->variant >= 0 && d->variant <= 2, "case_encoder_chain: variant must be 0 (full), 1 (tail) or 2 (head)");
   const bool head = d->variant == enc_chain::VAR_HEAD, tail = d->variant == enc_chain::VAR_TAIL;
-  if (!head) CASE_REQUIRE(resid && bo && b1 && b2 && ln2_g && ln2_b && scratch, "case_encoder_chain: the layer stages need resid, biases, LN2 and the scratch slab");
+  if (!head) CASE_REQUIRE(resid && bo && b1 && b2 && ln2_g && ln2_b, "case_encoder_chain: the layer stages need resid, biases and LN2");
   if (!tail) CASE_REQUIRE(bqkv && ln1n_g && ln1n_b && qkv_out, "case_encoder_chain: the LN + QKV stage needs its parameters and qkv_out");
-  for (const void* p : {x_in, resid, packed, (const void*)s_out, (const void*)qkv_out, (const void*)scratch, (const void*)bo, (const void*)b1,
-                        (const void*)b2, (const void*)bqkv, (const void*)ln2_g, (const void*)ln2_b, (const void*)ln1n_g, (const void*)ln1n_b})
+  for (const void* p : {x_in, resid, packed, (const void*)s_out, (const void*)qkv_out, (const void*)bo, (const void*)b1, (const void*)b2,
+                        (const void*)bqkv, (const void*)ln2_g, (const void*)ln2_b, (const void*)ln1n_g, (const void*)ln1n_b})
     CASE_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "case_encoder_chain: operands must be 16-byte aligned");
   enc_chain::Args a;
   a.ctx = (const bf16_t*)x_in;
@@ -430,7 +540,6 @@ extern "C" int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_i
   a.g2 = ln2_g; a.be2 = ln2_b; a.g1n = ln1n_g; a.be1n = ln1n_b;
   a.s_out = (bf16_t*)s_out;
   a.qkv_out = (bf16_t*)qkv_out;
-  a.scratch = (bf16_t*)scratch;
   a.M = d->rows;
   a.eps2 = d->eps_ln2;
   a.eps1n = d->eps_ln1_next;
@@ -439,7 +548,6 @@ extern "C" int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_i
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  if (cus > 256) cus = 256;  // the scratch slab is sized for 256 workgroups
   switch (d->variant) {
     case enc_chain::VAR_FULL: return enc_chain::launch<enc_chain::VAR_FULL>(a, cus, (hipStream_t)stream);
     case enc_chain::VAR_TAIL: return enc_chain::launch<enc_chain::VAR_TAIL>(a, cus, (hipStream_t)stream);

@@ -116,7 +116,6 @@ def cast(x, dtype):
 # single-launch path (tests replay the same fixtures under both; A/B measurements)
 ENCODER_CHAIN = "auto"
 _chain_packs = {}
-_chain_scratch = {}
 
 
 def encoder_chain_supported(x, width, ffn_width, needs_grad):
@@ -156,11 +155,6 @@ def encoder_chain(variant, x_in, resid, layer, next_layer):
     d.eps_ln1_next = 0.0 if nxt is None else nxt.norm1.eps
     s_out = torch.empty(x_in.shape, dtype=torch.bfloat16, device=dev)
     qkv = None if nxt is None else torch.empty(x_in.shape[0], x_in.shape[1], 1536, dtype=torch.bfloat16, device=dev)
-    scratch = None
-    if lay is not None:
-        scratch = _chain_scratch.get(dev)
-        if scratch is None:
-            scratch = _chain_scratch[dev] = torch.empty(A.lib.case_encoder_chain_scratch_bytes() // 2, dtype=torch.bfloat16, device=dev)
     x_in = x_in if x_in.is_contiguous() else x_in.contiguous()
     if resid is not None and not resid.is_contiguous():
         resid = resid.contiguous()
@@ -169,7 +163,7 @@ def encoder_chain(variant, x_in, resid, layer, next_layer):
            _ptr(None if lay is None else f32(lay.linear2.bias)), _ptr(None if nxt is None else f32(nxt.self_attn.in_proj_bias)),
            _ptr(None if lay is None else f32(lay.norm2.weight)), _ptr(None if lay is None else f32(lay.norm2.bias)),
            _ptr(None if nxt is None else f32(nxt.norm1.weight)), _ptr(None if nxt is None else f32(nxt.norm1.bias)),
-           _ptr(s_out), _ptr(qkv), _ptr(scratch), _stream())
+           _ptr(s_out), _ptr(qkv), _stream())
     return s_out, qkv
 
 

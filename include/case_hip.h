@@ -344,8 +344,8 @@ int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64
  *   variant 2 (head):  layer 0: x_in = embedding output; writes s_out = LN1(x_in), qkv_out; the layer-stage arguments may be null
  * Weights are passed PRE-PACKED (case_encoder_chain_pack: bf16 row-major [512, 512] x 3 and [1536, 512] -> MFMA fragment order,
  * case_encoder_chain_packed_bytes() bytes; any matrix may be null for the variants that do not read it); biases and LayerNorm
- * parameters f32.  scratch: case_encoder_chain_scratch_bytes() bytes (variants 0 / 1).  Of the 20 activation passes over HBM that
- * the same chain makes as single GEMM / LayerNorm launches, 6 remain (x_in, resid in; s', qkv' out).
+ * parameters f32.  Of the 20 activation passes over HBM that the same chain makes as single GEMM / LayerNorm launches, 6 remain
+ * (x_in, resid in; s', qkv' out).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t rows;   /* tokens (sequences x length) */
@@ -354,11 +354,10 @@ typedef struct {
   float eps_ln2, eps_ln1_next;
 } CaseEncoderChainDesc;
 int64_t case_encoder_chain_packed_bytes(void);
-int64_t case_encoder_chain_scratch_bytes(void);
 int case_encoder_chain_pack(const void* wo, const void* w1, const void* w2, const void* wqkv, void* packed, case_stream_t stream);
 int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_in, const void* resid, const void* packed, const float* bo,
                        const float* b1, const float* b2, const float* bqkv, const float* ln2_g, const float* ln2_b,
-                       const float* ln1n_g, const float* ln1n_b, void* s_out, void* qkv_out, void* scratch, case_stream_t stream);
+                       const float* ln1n_g, const float* ln1n_b, void* s_out, void* qkv_out, case_stream_t stream);
 
 /* Greedy post-processing on the device (common/Utils.py:200-217 to_sentence): per row of ids [B, T] drop the BOS / PAD ids and
  * everything from the first EOS on; out [B, T] holds the kept ids front-packed (pad behind), len [B] their count.  One host
