@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #define EC_REQUEST(dst)                                                                                   \
   {                                                                                                       \
     const int so_ = wstep * STEP_BYTES;                                                                   \
-    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) dst[nb] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + nb * 1024, so_, 0); \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) dst[nb] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so_ + nb * 1024, 0); \
     wstep = wstep + 1 == NSTEP ? 0 : wstep + 1;                                                           \
   }
   EC_REQUEST(wa)
@@ -432,10 +432,13 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
         const float eps = st == 0 ? g.eps2 : g.eps1n;
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-          const f32x4* ps = reinterpret_cast<const f32x4*>(stats + (tb * 16 + lt) * NWAVE * 2);
-          const f32x4 p0 = ps[0], p1 = ps[1], p2 = ps[2], p3 = ps[3];
-          const float s1 = ((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]));
-          const float s2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]));
+          // lane group lg adds the partial sums of waves 2 lg and 2 lg + 1 (one 16-byte read), two cross-lane adds finish the row
+          const f32x4 p = *reinterpret_cast<const f32x4*>(stats + ((tb * 16 + lt) * NWAVE + 2 * lg) * 2);
+          float s1 = p[0] + p[2], s2 = p[1] + p[3];
+          s1 += __shfl_xor(s1, 16);
+          s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
           mean[tb] = s1 * (1.f / E);
           rstd[tb] = rsqrtf(fmaxf(s2 * (1.f / E) - mean[tb] * mean[tb], 0.f) + eps);
         }
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
           to_rows(lo, hi, w0, w1);
           *reinterpret_cast<u32x4*>(pa + tb * 16384) = w0;
           *reinterpret_cast<u32x4*>(pb + tb * 16384) = w1;
-          if (st == 2) {  // s' (FULL) or the layer output (TAIL), row-major
+          if (st == 2) {  // s' (FULL) or the layer output (TAIL), row-major.  (Copying it out of X at the end of the tile instead, so
+            // that the stores retire under the next tile's DMA, was measured: the DMA wait grew by what the Q stages gained.)
             const int vo = v_row + tb * 16 * E * 2;  // per-lane offset, immediate soffset 0: see the QKV stores
             __builtin_amdgcn_raw_buffer_store_b128(w0, rso, vo, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(w1, rso, vo + 16, 0, 0);

@@ -113,7 +113,8 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
 
 # bf16 bars of the greedy fixtures, from the measured errors (profiles/r03_parity_errors.json): probabilities behind the 40x-sharpened
 # pointer logits move by a few per cent in bf16; ids are asserted wherever the reference's margin is above GREEDY_MARGIN_BAR.
-GREEDY_BARS = {"fp32": dict(rank=1e-3, prob=2e-3, margin_bar=1e-3), "bf16_auto": dict(rank=2e-2, prob=6e-2, margin_bar=6e-2)}
+# (rank = the passage-selection logits behind 8 + 5 ReLU blocks: 2.2e-2 of their scale measured for Masque in bf16.)
+GREEDY_BARS = {"fp32": dict(rank=1e-3, prob=2e-3, margin_bar=1e-3), "bf16_auto": dict(rank=3e-2, prob=6e-2, margin_bar=6e-2)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16_auto"])
