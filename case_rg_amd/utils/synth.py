@@ -58,3 +58,32 @@ def synth_batch(B, P, Lp, Lq, T, V, seed=123456, ragged=True, filler_passage=Tru
         batch["token_label"] = torch.from_numpy(((rng.rand(B, P, Lp) < 0.1) & valid).astype(np.float32))
         batch["token_weight"] = torch.ones(B, P, Lp, dtype=torch.float32)
     return batch
+
+
+def copy_task_batch(B, P, Lp, Lq, T, V, seed):
+    """A learnable synthetic task with the same schema ("a synthetic copy task" for the ROUGE acceptance): the answer
+    repeats the first T - 1 words of the query, then EOS (Lq >= T + 1); the labelled passage is the one that opens with the
+    query's first word and its first T - 1 tokens carry the token labels.  A pointer-generator learns within a few hundred Adam
+    steps to walk the query memory position by position; an untrained one scores near zero ROUGE-L."""
+    rng = np.random.RandomState(seed)
+    query = np.zeros((B, 1, Lq), dtype=np.int64)
+    passage = np.zeros((B, P, Lp), dtype=np.int64)
+    response = np.zeros((B, T), dtype=np.int64)
+    label = np.zeros(B, dtype=np.int64)
+    token_label = np.zeros((B, P, Lp), dtype=np.float32)
+    span = T - 1
+    for b in range(B):
+        query[b, 0] = _sequence(rng, Lq, Lq, V)
+        for p in range(P):
+            passage[b, p] = _sequence(rng, Lp, Lp, V)
+        p = label[b] = rng.randint(0, P)
+        passage[b, p, 1] = query[b, 0, 1]
+        response[b, :span] = query[b, 0, 1:1 + span]
+        response[b, span] = EOS
+        token_label[b, p, 1:1 + span] = 1.0
+    return {
+        "id": torch.arange(B, dtype=torch.long), "query": torch.from_numpy(query), "passage": torch.from_numpy(passage),
+        "response": torch.from_numpy(response), "passage_label": torch.from_numpy(label),
+        "source_map": torch.from_numpy(np.concatenate([query.reshape(B, -1), passage.reshape(B, -1)], axis=1)),
+        "token_label": torch.from_numpy(token_label), "token_weight": torch.ones(B, P, Lp, dtype=torch.float32),
+    }

@@ -278,12 +278,27 @@ def test_greedy_early_stop_and_graph_replay(ns):
         assert ns.to_sentence(early, i2v_eos) == ns.to_sentence(full, i2v_eos)
 
 
+def _sharpen_heads(model, v_gain=40.0, gen_gain=4.0):
+    """Decisive decoding without training: scale the last linear maps in front of the softmaxes (pointer heads' ``v``, vocabulary
+    projection), as the production-geometry greedy fixtures do (tests/golden/cases.py: PROD_TEST_GAIN).  The top-1 / top-2 margins
+    then sit well above bf16 resolution, which is the property a trained model has and a plain random one lacks."""
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("response_generation.decoder.attns.") and n.endswith(".v.weight"):
+                p.mul_(v_gain)
+            if n in ("response_generation.decoder.gen.2.weight", "response_generation.decoder.gen.1.weight"):
+                p.mul_(gen_gain)
+    return model
+
+
 def test_rouge_l_of_greedy_answers_within_0p2_of_the_oracle(ns):
-    """North-star acceptance in miniature: a synthetic dev set is decoded greedily by the HIP model (fp32 and bf16) and by the
-    CPU oracle with the same weights; ROUGE-L (the reference's metric, pinned by tests/golden/rouge_l.npz) of each against the
-    ground-truth answers must agree within 0.2 points in the parity (fp32) mode.  The model is UNTRAINED (random weights, gain 3):
-    its top-1 / top-2 margins are often below bf16 resolution, so the bf16 run flips tokens that a trained model would not; it is
-    held to 0.5 points on the 96-item set and its measured difference is recorded."""
+    """North-star acceptance in miniature ("ROUGE-L on dev within 0.2 of reference"): a synthetic dev set is decoded greedily by the
+    HIP model (fp32 AND bf16) and by the CPU oracle with the same weights; ROUGE-L (the reference's metric, pinned by
+    tests/golden/rouge_l.npz) of each against the ground-truth answers must agree within 0.2 points in BOTH modes.  The weights are
+    random with sharpened output heads (see _sharpen_heads): a plain random model has top-1 / top-2 margins below bf16 resolution
+    (round 2: 0.31 points in bf16); training the oracle on a synthetic copy task for 200-300 Adam steps in the build container did
+    not converge to a decoding that differs from "uniform over the query words" within the time a test may take (recorded in
+    DESIGN.md), so the decisiveness is set directly instead of learned."""
     import case_rg_amd
     import oracle
     from case_rg_amd.evaluation import eval_rouge_l
@@ -292,22 +307,25 @@ def test_rouge_l_of_greedy_answers_within_0p2_of_the_oracle(ns):
     v2i, i2v = make_vocab(V_)
     batch = synth_batch(96, 3, 16, 8, T, V_, seed=777, model="case")
     truth = [" ".join(w) for w in oracle.to_sentence(batch["response"].tolist(), i2v)]
-    ref_model = fill_params(oracle.CaSE(4, T, i2v, v2i, 64), 21, gain=3.0).eval()
+    ref_model = _sharpen_heads(fill_params(oracle.CaSE(4, T, i2v, v2i, 64), 21, gain=3.0)).eval()
     with torch.no_grad():
         ans = ref_model(dict(batch), method="test")["answer"]
     want = eval_rouge_l([" ".join(w) for w in oracle.to_sentence(ans.tolist(), i2v)], [[t] for t in truth])
-    scores = {}
+    scores, same = {}, {}
     for dt in (torch.float32, torch.bfloat16):
         case_rg_amd.set_compute_dtype(dt)
         try:
-            model = fill_params(ns.CaSE(4, T, i2v, v2i, 64), 21, gain=3.0).cuda().eval()
+            model = _sharpen_heads(fill_params(ns.CaSE(4, T, i2v, v2i, 64), 21, gain=3.0)).cuda().eval()
             with torch.no_grad():
                 got = model({k: v.cuda() for k, v in batch.items()}, method="test")["answer"]
             scores[str(dt)] = eval_rouge_l([" ".join(w) for w in model.to_sentence(None, got)], [[t] for t in truth])
+            same[str(dt)] = float((got.cpu() == ans).all(dim=1).float().mean())
         finally:
             case_rg_amd.set_compute_dtype(torch.float32)
     record_error("rouge_l_synthetic_dev", "fp32", "rouge_l_points_vs_oracle", abs(scores["torch.float32"] - want), 0.2)
-    record_error("rouge_l_synthetic_dev", "bf16_auto", "rouge_l_points_vs_oracle", abs(scores["torch.bfloat16"] - want), 0.5)
+    record_error("rouge_l_synthetic_dev", "bf16_auto", "rouge_l_points_vs_oracle", abs(scores["torch.bfloat16"] - want), 0.2)
+    record_error("rouge_l_synthetic_dev", "bf16_auto", "fraction_of_answers_identical_to_oracle", 1.0 - same["torch.bfloat16"], 0.25)
     assert want > 0.0, "degenerate dev set"
+    assert len(set(map(tuple, ans.tolist()))) > 8, "the oracle's answers collapsed to a few strings"
     assert abs(scores["torch.float32"] - want) <= 0.2, "fp32: ROUGE-L %.2f vs oracle %.2f" % (scores["torch.float32"], want)
-    assert abs(scores["torch.bfloat16"] - want) <= 0.5, "bf16: ROUGE-L %.2f vs oracle %.2f" % (scores["torch.bfloat16"], want)
+    assert abs(scores["torch.bfloat16"] - want) <= 0.2, "bf16: ROUGE-L %.2f vs oracle %.2f" % (scores["torch.bfloat16"], want)
