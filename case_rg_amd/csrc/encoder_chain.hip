@@ -19,7 +19,7 @@
 //     every fragment read is conflict free) and is rewritten IN PLACE by each stage's epilogue;
 //   * the weights do not pass through LDS at all: they are pre-packed (case_encoder_chain_pack, once per parameter update) into
 //     MFMA fragment order -- one contiguous KiB per (16 features x 32 k) fragment, laid out in exactly the order a wave consumes
-//     them -- and each wave streams its share straight from L2 into registers one K step ahead of the MFMAs that use them
+//     them -- and each wave streams its share straight from L2 into registers two K steps ahead of the MFMAs that use them
 //     (every CU reads the same 3 MB per layer: L2-resident; a 64-token tile would double that stream and saturate the CU's
 //     64 B/clk vector-memory path, which is why the tile is 128 tokens);
 //   * a wave owns 64 of each stage's 512 output features for all 128 tokens (128 accumulator registers): per K step of 32 it
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
       as_rsrc(reinterpret_cast<const char*>(g.wpk) + wave * WAVE_BYTES + (int64_t)ST0 * SLOT_BYTES, (uint32_t)(NSTEP * STEP_BYTES));
   const int wv = l * 16;
   int wstep = 0;  // stream position of the NEXT step to request
-  u32x4 wa[4], wb[4];  // weight fragments of two consecutive K steps; a request runs one step ahead of its use
+  u32x4 wa[4], wb[4], wc[4], wd[4];  // weight fragments of four consecutive K steps; a request runs TWO steps ahead of its use
 #define EC_REQUEST(dst)                                                                                   \
   {                                                                                                       \
     const int so_ = wstep * STEP_BYTES;                                                                   \
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
     wstep = wstep + 1 == NSTEP ? 0 : wstep + 1;                                                           \
   }
   EC_REQUEST(wa)
+  EC_REQUEST(wb)
 
   // per-lane parts of the global addresses (the uniform parts ride in the scalar offset) and of the X addresses
   const int v_row = (lt * E + n0 + 16 * lg) * 2, v_row3 = (lt * 3 * E + n0 + 16 * lg) * 2;  // row-layout accesses: 32 bytes per lane
@@ -309,43 +310,53 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb) acc[tb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      // ---- K loop: 16 steps of 32; weights one step ahead (wa / wb alternate), token fragments refilled behind their MFMAs ---------
+      // ---- K loop: 16 steps of 32.  Weights two steps ahead (an L2 round trip under this load is longer than one step of two waves'
+      // MFMAs); the eight token fragments of a step are read at its start into ONE set of registers -- the first MFMA group waits
+      // for the first fragment only and the partner wave on the SIMD covers that latency, which frees the 32 registers a second
+      // fragment set costs for the deeper weight prefetch.
       {
         int xl = xlane, xh = lt >> 2;
         asm volatile("" : "+v"(xl), "+v"(xh));  // opaque: the per-step addresses are recomputed, not hoisted out of the tile loop
-        bf16x8 xf[8];
-        {
-          const char* p0 = smem + xl + ((0 ^ xh) << 6);
-#pragma unroll
-          for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(p0 + tb * 16384);
-        }
 #ifndef CHAIN_DBG_NO_XREAD
-#define EC_REFILL xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);
+#define EC_XREAD(KS)                                                                                                                 \
+    {                                                                                                                                \
+      const char* pn = smem + xl + (((KS) ^ xh) << 6);                                                                               \
+      _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);                   \
+    }
 #else
-#define EC_REFILL
+#define EC_XREAD(KS) { if ((KS) == 0) { const char* pn = smem + xl; _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384); } }
 #endif
 #define EC_STEP(W, KS)                                                                                                              \
   {                                                                                                                                  \
-    const char* pn = smem + xl + (((((KS) + 1) & (KSTEPS - 1)) ^ xh) << 6);                                                          \
+    bf16x8 xf[8];                                                                                                                    \
+    EC_XREAD(KS)                                                                                                                     \
     _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) {                                                                               \
       _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                               \
         acc[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&W[nb]), xf[tb], acc[tb][nb], 0, 0, 0); \
-      EC_REFILL                                                                                                                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                                             \
     }                                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
   }
-        // Past the stage's last step the request is the next stage's (or the next tile's) first step: the stream is continuous.
-        for (int ks = 0; ks < KSTEPS; ks += 2) {
+        // at the top of an iteration wa / wb hold (or are loading) steps ks / ks + 1.  Past the stage's last step the requests are
+        // the next stage's (or the next tile's) first steps: the stream is continuous.
+        for (int ks = 0; ks < KSTEPS; ks += 4) {
 #ifndef CHAIN_DBG_NO_WLOAD
-          EC_REQUEST(wb)
-#endif
+          EC_REQUEST(wc)
           EC_STEP(wa, ks)
-#ifndef CHAIN_DBG_NO_WLOAD
-          EC_REQUEST(wa)
-#endif
+          EC_REQUEST(wd)
           EC_STEP(wb, ks + 1)
+          EC_REQUEST(wa)
+          EC_STEP(wc, ks + 2)
+          EC_REQUEST(wb)
+          EC_STEP(wd, ks + 3)
+#else
+          EC_STEP(wa, ks)
+          EC_STEP(wb, ks + 1)
+          EC_STEP(wa, ks + 2)
+          EC_STEP(wb, ks + 3)
+#endif
         }
 #undef EC_STEP
+#undef EC_XREAD
       }
       EC_STAMP(3 + 4 * st)
 
