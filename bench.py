@@ -483,8 +483,8 @@ def spawn_ranks(a):
 
 def main():
     a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(a)
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("CASE_BENCH_FORCE_SPAWN")):
+        spawn_ranks(a)  # CASE_BENCH_FORCE_SPAWN: rehearse the self-launch with --gpus 1 on a one-GPU box
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and not (world == 1 and a.gpus <= 1):

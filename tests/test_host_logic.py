@@ -2,6 +2,7 @@
 schema, helpers restated from common/Utils.py, LR schedule, dropout counter bookkeeping."""
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -195,6 +196,19 @@ def test_special_id_cache_follows_the_vocabulary_object():
     assert Utils._specials(b) == (6, 5, 7) and Utils._special_ids[0] is b
     assert Utils._specials(a) == (1, 0, 2)
     assert Utils._specials(["x", "y"]) == (-1, -1, -1)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself_or_fails_loudly():
+    """`python bench.py --gpus N` outside torch.distributed.run must not silently run one rank: it spawns the N
+    ranks as a child process -- or, when the node has fewer GPUs (here: none), says so; and a WORLD_SIZE that contradicts --gpus is
+    refused.  (The spawn itself is rehearsed on the GPU box with CASE_BENCH_FORCE_SPAWN=1 --gpus 1.)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout) and "GPU(s)" in (r.stderr + r.stdout), r.stderr[-300:]
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout), r.stderr[-300:]
 
 
 def test_bench_flop_model_matches_the_survey():
