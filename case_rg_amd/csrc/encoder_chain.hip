@@ -192,6 +192,55 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
   // row-layout write (after to_rows): features n0 + 16 lg .. + 15 = chunks 8 wave + 2 lg and + 1 -> xr + ((xq2) << 4), xr + ((xq2 ^ 1) << 4)
   const int xq2 = lt ^ (8 * (wave & 1) + 2 * lg), xr = lt * 1024 + (wave >> 1) * 256;
 
+#ifndef CHAIN_DBG_NO_XREAD
+#define EC_XREAD(KS)                                                                                                                 \
+    {                                                                                                                                \
+      const char* pn = smem + xl + (((KS) ^ xh) << 6);                                                                               \
+      _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);                   \
+    }
+#else
+#define EC_XREAD(KS) { if ((KS) == 0) { const char* pn = smem + xl; _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384); } }
+#endif
+#define EC_STEP(W, KS)                                                                                                              \
+  {                                                                                                                                  \
+    bf16x8 xf[8];                                                                                                                    \
+    EC_XREAD(KS)                                                                                                                     \
+    _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) {                                                                               \
+      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                               \
+        acc[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&W[nb]), xf[tb], acc[tb][nb], 0, 0, 0); \
+    }                                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+  }
+#ifndef CHAIN_DBG_NO_WLOAD
+#define EC_KLOOP                                                                                              \
+  {                                                                                                           \
+    int xl = xlane, xh = lt >> 2;                                                                             \
+    asm volatile("" : "+v"(xl), "+v"(xh)); /* opaque: the per-step addresses are recomputed, not hoisted */   \
+    for (int ks = 0; ks < KSTEPS; ks += 4) {                                                                  \
+      EC_REQUEST(wc)                                                                                          \
+      EC_STEP(wa, ks)                                                                                         \
+      EC_REQUEST(wd)                                                                                          \
+      EC_STEP(wb, ks + 1)                                                                                     \
+      EC_REQUEST(wa)                                                                                          \
+      EC_STEP(wc, ks + 2)                                                                                     \
+      EC_REQUEST(wb)                                                                                          \
+      EC_STEP(wd, ks + 3)                                                                                     \
+    }                                                                                                         \
+  }
+#else
+#define EC_KLOOP                                                                                              \
+  {                                                                                                           \
+    int xl = xlane, xh = lt >> 2;                                                                             \
+    asm volatile("" : "+v"(xl), "+v"(xh));                                                                    \
+    for (int ks = 0; ks < KSTEPS; ks += 4) {                                                                  \
+      EC_STEP(wa, ks)                                                                                         \
+      EC_STEP(wb, ks + 1)                                                                                     \
+      EC_STEP(wa, ks + 2)                                                                                     \
+      EC_STEP(wb, ks + 3)                                                                                     \
+    }                                                                                                         \
+  }
+#endif
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = (int64_t)tile * TOK;
     const int rows = (int)(g.M - row0 < TOK ? g.M - row0 : TOK);
@@ -303,8 +352,11 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
       __syncthreads();
     }
 
-    for (int st = ST0; st < ST1; ++st) {
-      if (st == 1 || st >= 3) {  // no residual in front of the GEMM: the bias is added in the epilogue
+    // Two stage loops (row-local stages 0..2, then Q / K / V) instead of one with a branch: with a single loop hipcc keeps the
+    // Q / K / V epilogue's values live through the GELU epilogue and spills 160 registers per lane and tile (2.2 GB of scratch
+    // traffic per launch in the PMC counters); split, the FULL variant spills 6.
+    for (int st = ST0; st < (ST1 < 3 ? ST1 : 3); ++st) {
+      if (st == 1) {  // no residual in front of the GEMM: the bias is added in the epilogue
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb)
 #pragma unroll
@@ -314,81 +366,10 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
       // MFMAs); the eight token fragments of a step are read at its start into ONE set of registers -- the first MFMA group waits
       // for the first fragment only and the partner wave on the SIMD covers that latency, which frees the 32 registers a second
       // fragment set costs for the deeper weight prefetch.
-      {
-        int xl = xlane, xh = lt >> 2;
-        asm volatile("" : "+v"(xl), "+v"(xh));  // opaque: the per-step addresses are recomputed, not hoisted out of the tile loop
-#ifndef CHAIN_DBG_NO_XREAD
-#define EC_XREAD(KS)                                                                                                                 \
-    {                                                                                                                                \
-      const char* pn = smem + xl + (((KS) ^ xh) << 6);                                                                               \
-      _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);                   \
-    }
-#else
-#define EC_XREAD(KS) { if ((KS) == 0) { const char* pn = smem + xl; _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384); } }
-#endif
-#define EC_STEP(W, KS)                                                                                                              \
-  {                                                                                                                                  \
-    bf16x8 xf[8];                                                                                                                    \
-    EC_XREAD(KS)                                                                                                                     \
-    _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) {                                                                               \
-      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                               \
-        acc[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&W[nb]), xf[tb], acc[tb][nb], 0, 0, 0); \
-    }                                                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                               \
-  }
-        // at the top of an iteration wa / wb hold (or are loading) steps ks / ks + 1.  Past the stage's last step the requests are
-        // the next stage's (or the next tile's) first steps: the stream is continuous.
-        for (int ks = 0; ks < KSTEPS; ks += 4) {
-#ifndef CHAIN_DBG_NO_WLOAD
-          EC_REQUEST(wc)
-          EC_STEP(wa, ks)
-          EC_REQUEST(wd)
-          EC_STEP(wb, ks + 1)
-          EC_REQUEST(wa)
-          EC_STEP(wc, ks + 2)
-          EC_REQUEST(wb)
-          EC_STEP(wd, ks + 3)
-#else
-          EC_STEP(wa, ks)
-          EC_STEP(wb, ks + 1)
-          EC_STEP(wa, ks + 2)
-          EC_STEP(wb, ks + 3)
-#endif
-        }
-#undef EC_STEP
-#undef EC_XREAD
-      }
+      EC_KLOOP
       EC_STAMP(3 + 4 * st)
 
       // ---- epilogues ---------------------------------------------------------------------------------------------------------------
-      if (st >= 3) {  // Q / K / V: + bias, pack, lane-row transpose, store [M, 1536] as 16-byte vectors
-        const float* bias = par + P_BQKV + 512 * (st - 3) + n0 + 4 * lg;
-        f32x4 b4[4];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bias + 16 * nb);
-#pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
-          uint32_t lo[4], hi[4];
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            lo[nb] = f32x2_to_bf16x2(acc[tb][nb][0] + b4[nb][0], acc[tb][nb][1] + b4[nb][1]);
-            hi[nb] = f32x2_to_bf16x2(acc[tb][nb][2] + b4[nb][2], acc[tb][nb][3] + b4[nb][3]);
-          }
-          u32x4 v0, v1;
-          to_rows(lo, hi, v0, v1);
-#ifndef CHAIN_DBG_NO_QSTORE
-          // The whole offset rides in the per-lane register, the scalar offset stays the immediate 0: a 16-byte buffer store whose
-          // soffset is an SGPR reads its data registers over several cycles and hipcc (ROCm 7.2) only guards the immediate form --
-          // VALU writes scheduled right behind the store then reach the last lanes of each half (seen here as wrong / NaN values
-          // in lanes 28-31 / 60-63 of single token blocks, timing dependent); the same hazard as in gemm8w.inc's drain_pass.
-          const int vo = v_row3 + tb * 16 * 3 * E * 2 + 512 * (st - 3) * 2;
-          __builtin_amdgcn_raw_buffer_store_b128(v0, rqkv, vo, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(v1, rqkv, vo + 16, 0, 0);
-#endif
-        }
-        EC_STAMP(6 + 4 * st)
-        continue;  // X is unchanged: the next stage's K loop may start at once (the waves drift apart here, on purpose)
-      }
       if (st == 1) {
         // FFN1: a = gelu(acc + b1) goes into X where s2 stood; the s2 this lane overwrites seeds its FFN2 accumulators (b2 + s2)
         __syncthreads();  // every wave is behind its K loop: nobody reads X any more
@@ -496,10 +477,48 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
       EC_STAMP(5 + 4 * st)
       __syncthreads();  // X holds the next stage's operand
       EC_STAMP(6 + 4 * st)
+        }
+    for (int st = (ST0 > 3 ? ST0 : 3); st < ST1; ++st) {  // Q / K / V: + bias, pack, lane-row transpose, store [M, 1536] as 16-byte vectors
+#pragma unroll
+      for (int tb = 0; tb < 8; ++tb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[tb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      EC_KLOOP
+      EC_STAMP(3 + 4 * st)
+
+      const float* bias = par + P_BQKV + 512 * (st - 3) + n0 + 4 * lg;
+      f32x4 b4[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bias + 16 * nb);
+#pragma unroll
+      for (int tb = 0; tb < 8; ++tb) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          lo[nb] = f32x2_to_bf16x2(acc[tb][nb][0] + b4[nb][0], acc[tb][nb][1] + b4[nb][1]);
+          hi[nb] = f32x2_to_bf16x2(acc[tb][nb][2] + b4[nb][2], acc[tb][nb][3] + b4[nb][3]);
+        }
+        u32x4 v0, v1;
+        to_rows(lo, hi, v0, v1);
+#ifndef CHAIN_DBG_NO_QSTORE
+        // The whole offset rides in the per-lane register, the scalar offset stays the immediate 0: a 16-byte buffer store whose
+        // soffset is an SGPR reads its data registers over several cycles and hipcc (ROCm 7.2) only guards the immediate form --
+        // VALU writes scheduled right behind the store then reach the last lanes of each half (seen here as wrong / NaN values
+        // in lanes 28-31 / 60-63 of single token blocks, timing dependent); the same hazard as in gemm8w.inc's drain_pass.
+        const int vo = v_row3 + tb * 16 * 3 * E * 2 + 512 * (st - 3) * 2;
+        __builtin_amdgcn_raw_buffer_store_b128(v0, rqkv, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v1, rqkv, vo + 16, 0, 0);
+#endif
+      }
+      EC_STAMP(6 + 4 * st)
+      // X is unchanged: the next stage's K loop may start at once (the waves drift apart here, on purpose)
     }
     __syncthreads();  // the last K loops are done before the next tile's DMA overwrites X
     EC_STAMP(27)
   }
+#undef EC_KLOOP
+#undef EC_STEP
+#undef EC_XREAD
 #undef EC_REQUEST
 }
 
