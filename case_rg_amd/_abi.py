@@ -59,6 +59,9 @@ SIGNATURES = {
     "case_attention_decode_supported": [i64],
     "case_attention_decode": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr],
     "case_attention_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_attention_scores_supported": [C.POINTER(AttnDesc)],
+    "case_attention_scores_fwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_attention_scores_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],
     "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],
     "case_mask_rows": [ptr, ptr, ptr, i64, i64, i32, ptr],

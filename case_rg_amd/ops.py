@@ -618,6 +618,7 @@ def _src_key(t):
 #   "fused"   the fused kernels wherever they are built (64, 96, 320, 480: forward and backward)
 #   "unfused" never fused (tests run the production-shape fixtures under both)
 ATTENTION_MODE = "auto"
+SCORES_FUSED = True  # the GEMM + softmax + GEMM path keeps its scores in the score GEMM's accumulators where K17 covers the shape
 _FUSED_TRAINING = (64, 96)
 _FUSED_INFERENCE = (64, 96, 320)
 
@@ -732,6 +733,13 @@ class AttentionFn(Function):
         return (out[0], out[1], out[2]) + (None,) * 8
 
     @staticmethod
+    def _scores_fused(a_src, b_src, a_off, b_off, heads, d, Lq, Lk, causal):
+        """K17 covers this product (bf16, head_dim % 64 == 0, Lk <= 384, Lk % 8 == 0, no causal mask, 16-byte aligned slices)."""
+        if not SCORES_FUSED or a_src.dtype != torch.bfloat16 or causal or d % 64 or Lk > 384 or Lk % 8:
+            return False
+        return all(t.shape[2] % 8 == 0 and off % 8 == 0 and t.data_ptr() % 16 == 0 for t, off in ((a_src, a_off), (b_src, b_off)))
+
+    @staticmethod
     def _probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha):
         """P = softmax(alpha Q K^T | masks) [N, h, Lq, Lk] and its dropped-out copy (same tensor when drop is None).
         The scores are kept in f32 between the GEMM and the softmax: a bf16 score of magnitude 16 carries an absolute error of
@@ -740,6 +748,14 @@ class AttentionFn(Function):
         N, Lq, _ = q_src.shape
         Lk = k_src.shape[1]
         dt = q_src.dtype
+        if AttentionFn._scores_fused(q_src, k_src, q_off, k_off, heads, d, Lq, Lk, causal):
+            # K17: the softmax rides in the score GEMM (a workgroup holds whole rows): no f32 score tensor
+            P = torch.empty(N, heads, Lq, Lk, dtype=dt, device=q_src.device)
+            Pd = torch.empty_like(P) if drop is not None else P
+            ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, k_src, causal, alpha, drop)
+            A.call("case_attention_scores_fwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(key_valid), _ptr(P),
+                   _ptr(Pd) if drop is not None else None, _stream())
+            return P, Pd
         S = torch.empty(N, heads, Lq, Lk, dtype=torch.float32, device=q_src.device)
         gemm(q_src, k_src, S, Lq, Lk, d, q_src.shape[2], k_src.shape[2], Lk, a_off=q_off, b_off=k_off, batch1=N, batch2=heads,
              sa=(Lq * q_src.shape[2], d), sb=(Lk * k_src.shape[2], d), sc=(heads * Lq * Lk, Lq * Lk), alpha=alpha)
@@ -778,15 +794,20 @@ class AttentionFn(Function):
             return bufs[key]
 
         gq, gk, gv = grad_of(q_src), grad_of(k_src), grad_of(v_src)
-        # dP = dO V^T
-        dP = torch.empty(N, heads, Lq, Lk, dtype=dt, device=dev)
-        gemm(dO, v_src, dP, Lq, Lk, d, E, Wv, Lk, b_off=v_off, batch1=N, batch2=heads, sa=(Lq * E, d), sb=(Lk * Wv, d), sc=pstr)
         # dV = Pd^T dO
         gemm(Pd, dO, gv, Lk, d, Lq, Lk, E, Wv, c_off=v_off, a_kmajor=True, b_kmajor=True, batch1=N, batch2=heads,
              sa=pstr, sb=(Lq * E, d), sc=(Lk * Wv, d))
-        # dS = softmax'(dP) in place
-        sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
-        A.call("case_softmax_bwd", sd, _ptr(dP), _ptr(P), _ptr(dP), _stream())
+        dP = torch.empty(N, heads, Lq, Lk, dtype=dt, device=dev)
+        if AttentionFn._scores_fused(dO, v_src, 0, v_off, heads, d, Lq, Lk, causal):
+            # K17: dS = softmax'(dO V^T) with the row sums in the GEMM's epilogue (dP itself is never written)
+            ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)
+            A.call("case_attention_scores_bwd", ad, _ptr(dO), _ptr(v_src, v_off), _ptr(P), _ptr(dP), _stream())
+        else:
+            # dP = dO V^T
+            gemm(dO, v_src, dP, Lq, Lk, d, E, Wv, Lk, b_off=v_off, batch1=N, batch2=heads, sa=(Lq * E, d), sb=(Lk * Wv, d), sc=pstr)
+            # dS = softmax'(dP) in place
+            sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
+            A.call("case_softmax_bwd", sd, _ptr(dP), _ptr(P), _ptr(dP), _stream())
         # dQ = alpha dS K ; dK = alpha dS^T Q
         gemm(dP, k_src, gq, Lq, d, Lk, Lk, Wk, Wq, b_off=k_off, c_off=q_off, b_kmajor=True, batch1=N, batch2=heads,
              sa=pstr, sb=(Lk * Wk, d), sc=(Lq * Wq, d), alpha=alpha)

@@ -202,6 +202,21 @@ int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, cons
                        const void* out, const float* lse, const void* dout, float* delta, void* dq, void* dk, void* dv,
                        case_stream_t stream);
 
+/* K17  probabilities of the GEMM -> softmax -> GEMM attention path (the training path of the head_dim 320 blocks,
+ * common/TransformerBlock.py:26; F.multi_head_attention_forward's bmm -> softmax -> dropout -> bmm) with the softmax in the score
+ * GEMM: one workgroup holds 128 query rows x all Lk keys, so no score tensor reaches memory.
+ *   case_attention_scores_fwd: p = softmax(scale q k^T | key_valid) as bf16 [N, heads, Lq, Lk]; with drop_p > 0 also
+ *     p_dropped = keep ? p / (1 - drop_p) : 0 (same counter RNG / element index as case_softmax_fwd); replaces case_gemm (f32
+ *     scores) + case_softmax_fwd.  Rows without a valid key give exact zeros.
+ *   case_attention_scores_bwd: ds = p (g - rowsum(g p)), g = keep ? (dout v^T) / (1 - drop_p) : 0, bf16 [N, heads, Lq, Lk];
+ *     replaces case_gemm (dP) + case_softmax_bwd.  dout is addressed with ldo / so, v with ldv / sv of the descriptor.
+ * Scope (case_attention_scores_supported(d) != 0): bf16, head_dim a multiple of 64, Lk <= 384 and a multiple of 8, not causal. */
+int case_attention_scores_supported(const CaseAttnDesc* d);
+int case_attention_scores_fwd(const CaseAttnDesc* d, const void* q, const void* k, const uint8_t* key_valid, void* p,
+                              void* p_dropped, case_stream_t stream);
+int case_attention_scores_bwd(const CaseAttnDesc* d, const void* dout, const void* v, const void* p, void* ds,
+                              case_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * elementwise / small reductions
  * ------------------------------------------------------------------------------------------- */

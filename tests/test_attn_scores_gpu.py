@@ -1,0 +1,139 @@
+"""K17 (csrc/attn_scores.hip): the probabilities of the GEMM -> softmax -> GEMM attention path with the softmax inside the score
+GEMM.  Reference arithmetic: F.multi_head_attention_forward behind nn.MultiheadAttention (common/TransformerBlock.py:26):
+softmax(q k^T / sqrt(d) + key padding) -> dropout -> @ v, and its autograd.  Checked against (a) an f32 torch restatement on the
+same bf16 inputs with the SAME dropout mask (read back from the kernel's own outputs), and (b) the two-kernel HIP path it
+replaces (case_gemm + case_softmax_*), which must see identical masks and probabilities equal to the last bf16 bit or two."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _inputs(N, heads, Lq, Lk, d, seed, packed):
+    g = torch.Generator().manual_seed(seed)
+    E = heads * d
+    if packed:  # self-attention: one [N, L, 3E] projection tensor, as in_proj produces it
+        qkv = (torch.randn(N, Lq, 3 * E, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+        srcs = (qkv, qkv, qkv, 0, E, 2 * E)
+    else:
+        q = (torch.randn(N, Lq, E, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+        kv = (torch.randn(N, Lk, 2 * E, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+        srcs = (q, kv, kv, 0, 0, E)
+    lens = torch.randint(max(1, Lk // 3), Lk + 1, (N,), generator=g)
+    lens[0] = Lk
+    valid = torch.arange(Lk)[None, :] < lens[:, None]
+    if N > 2:
+        valid[2] = False  # a sequence without any valid key: exact zeros everywhere
+    dO = (torch.randn(N, Lq, E, generator=g)).to(torch.bfloat16).to(DEV)
+    return srcs, valid.to(DEV), dO
+
+
+def _heads(t, off, heads, d):
+    N, L, _ = t.shape
+    return t[:, :, off:off + heads * d].reshape(N, L, heads, d).permute(0, 2, 1, 3).float()
+
+
+def _desc(ops, N, heads, Lq, Lk, d, q_src, k_src, v_src, drop):
+    return ops._attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, False, 1.0 / math.sqrt(d), drop)
+
+
+@pytest.mark.parametrize("N,heads,Lq,Lk,d,p_drop,packed", [
+    (3, 8, 384, 384, 320, 0.1, True),     # the cfg 2 block geometry
+    (3, 8, 384, 384, 320, 0.0, True),
+    (4, 2, 100, 200, 64, 0.1, False),     # ragged: a partial query tile, key quarters that end early / are empty
+    (3, 3, 130, 8, 128, 0.25, False),     # one key block only
+    (3, 1, 5, 376, 192, 0.0, False),
+])
+def test_scores_kernels_follow_the_f32_restatement(N, heads, Lq, Lk, d, p_drop, packed):
+    from case_rg_amd import _abi as A, ops
+    (q_src, k_src, v_src, q_off, k_off, v_off), valid, dO = _inputs(N, heads, Lq, Lk, d, 7 + Lq + d, packed)
+    drop = (p_drop, 1234, 77) if p_drop > 0 else None
+    ad = _desc(ops, N, heads, Lq, Lk, d, q_src, k_src, v_src, drop)
+    assert A.lib.case_attention_scores_supported(ad)
+    P = torch.full((N, heads, Lq, Lk), 7.0, dtype=torch.bfloat16, device=DEV)
+    Pd = torch.full_like(P, 7.0) if drop else None
+    kv8 = valid.to(torch.uint8)
+    A.call("case_attention_scores_fwd", ad, ops._ptr(q_src, q_off), ops._ptr(k_src, k_off), ops._ptr(kv8), ops._ptr(P),
+           ops._ptr(Pd) if drop else None, ops._stream())
+    # f32 restatement of the forward
+    q, k, v = _heads(q_src, q_off, heads, d), _heads(k_src, k_off, heads, d), _heads(v_src, v_off, heads, d)
+    S = (q @ k.transpose(-1, -2)) / math.sqrt(d)
+    S = S.masked_fill(~valid[:, None, None, :], float("-inf"))
+    P_ref = torch.softmax(S, dim=-1)
+    P_ref = torch.nan_to_num(P_ref, nan=0.0)  # rows without a valid key: zeros, as the HIP softmax defines them
+    assert torch.isfinite(P.float()).all()
+    assert (P.float() - P_ref).abs().max().item() <= 2.0 ** -8, (P.float() - P_ref).abs().max().item()
+    assert ((P.float() - P_ref).abs() <= 2.0 ** -8 * P_ref + 1e-6).all()  # one bf16 rounding of the f32 value
+    assert (P[~valid[:, None, None, :].expand_as(P)] == 0).all()
+    if N > 2:
+        assert (P[2] == 0).all()
+    if drop:
+        keep = Pd != 0
+        rate = 1.0 - keep[P > 0].float().mean().item()
+        assert abs(rate - p_drop) < 0.02, rate
+        want = (P_ref / (1.0 - p_drop))
+        assert ((Pd.float() - want).abs()[keep] <= 2.0 ** -8 * want[keep] + 1e-6).all()
+        # the softmax kernel of the two-kernel path draws the same mask from the same (seed, offset)
+        S32 = (S * 1.0).contiguous()
+        P2, Pd2 = torch.empty_like(P), torch.empty_like(P)
+        sd = ops._softmax_desc(N, heads, Lq, Lk, False, A.F32, A.BF16, drop)
+        A.call("case_softmax_fwd", sd, ops._ptr(S32), ops._ptr(kv8), None, ops._ptr(P2), ops._ptr(Pd2), ops._stream())
+        assert ((Pd2 != 0) == keep)[P2 > 0].all()
+    # backward: dS = P (g - rowsum(g P)), g = mask(dO V^T) / (1 - p), with the kernel's own P and mask
+    dS = torch.full_like(P, 7.0)
+    A.call("case_attention_scores_bwd", ad, ops._ptr(dO), ops._ptr(v_src, v_off), ops._ptr(P), ops._ptr(dS), ops._stream())
+    dOh = dO.reshape(N, Lq, heads, d).permute(0, 2, 1, 3).float()
+    g = dOh @ v.transpose(-1, -2)
+    if drop:
+        g = torch.where(keep, g / (1.0 - p_drop), torch.zeros_like(g))
+    Pf = P.float()
+    dS_ref = Pf * (g - (g * Pf).sum(-1, keepdim=True))
+    err = (dS.float() - dS_ref).abs()
+    scale = dS_ref.abs().amax(dim=-1, keepdim=True).clamp_min(1e-6)
+    assert torch.isfinite(dS.float()).all()
+    assert (err / scale).max().item() < 1.5e-2, (err / scale).max().item()  # bf16 output rounding + f32 summation order
+    rel_l2 = (dS.float() - dS_ref).norm() / dS_ref.norm().clamp_min(1e-12)
+    assert rel_l2.item() < 4e-3, rel_l2.item()
+
+
+def test_attention_op_uses_the_scores_kernels_and_agrees_with_the_two_kernel_path():
+    """ops.attention on the GEMM + softmax + GEMM path (what training runs at head_dim 320): K17 on / off give the same output
+    and gradients up to bf16 rounding; on, no f32 score tensor / case_softmax_* launch is left."""
+    from case_rg_amd import _abi as A, config, ops
+    import case_rg_amd
+    N, heads, L, d = 2, 8, 384, 320
+    (qkv, _, _, q_off, k_off, v_off), valid, dO = _inputs(N, heads, L, L, d, 5, True)
+    case_rg_amd.set_dropout(True)
+    calls, raw = {}, A.call
+
+    def counting(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return raw(name, *a)
+
+    res = {}
+    prev_mode = ops.ATTENTION_MODE
+    try:
+        ops.ATTENTION_MODE = "unfused"
+        for on in (True, False):
+            ops.SCORES_FUSED = on
+            config.manual_seed(99)
+            x = qkv.clone().requires_grad_(True)
+            calls.clear()
+            A.call = counting
+            out = ops.attention(x, x, x, q_off, k_off, v_off, heads, d, key_valid=valid, p_drop=0.1)
+            out.backward(dO)
+            A.call = raw
+            res[on] = (out.detach().float(), x.grad.float(), dict(calls))
+    finally:
+        A.call = raw
+        ops.SCORES_FUSED = True
+        ops.ATTENTION_MODE = prev_mode
+    (o1, g1, c1), (o0, g0, c0) = res[True], res[False]
+    assert c1.get("case_attention_scores_fwd") == 1 and c1.get("case_attention_scores_bwd") == 1
+    assert "case_softmax_fwd" not in c1 and "case_softmax_bwd" not in c1 and c1.get("case_gemm", 0) == c0.get("case_gemm", 0) - 2
+    assert "case_attention_scores_fwd" not in c0 and c0.get("case_softmax_fwd") == 1
+    assert (o1 - o0).norm() / o0.norm() < 5e-3
+    assert (g1 - g0).norm() / g0.norm() < 2e-2  # the two-kernel path rounds dP to bf16, K17 keeps it in f32
