@@ -31,6 +31,15 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 namespace attn_sc {
 
+// Cache policies, measured at cfg 2 (tools/scores_bench.py, forward / backward ms): default everywhere 0.715 / 0.575; streaming (nt)
+// loads of the query-side operand, which no other workgroup reads again, 0.699 / 0.565; nt result stores 0.757 / 0.617.
+#ifndef SC_NT_A
+#define SC_NT_A true
+#endif
+#ifndef SC_NT_ST
+#define SC_NT_ST 0
+#endif
+
 constexpr int TM = 128, TN = 384, BKE = 64, NTHR = 512;
 constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
 constexpr int STATS_OFF = 2 * STAGE, STATS_BYTES = TM * 4 * 8, LDS_BYTES = STATS_OFF + STATS_BYTES;
@@ -63,16 +72,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t as_rsrc(const void* p, uint32_
 }
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+template <bool NT>  // NT: streaming cache policy for bytes no other workgroup reads again (the query-side operand)
 __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory", "m0");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
-__device__ __forceinline__ int xcd_remap(int pid, int nwg) {  // consecutive work items share an XCD (the three query tiles of a
-  const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;  // (sequence, head) re-read the same keys from one L2)
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -88,6 +98,18 @@ __device__ __forceinline__ void pair_swap(uint32_t (&x)[2], uint32_t (&y)[2]) {
   }
 }
 
+#ifdef SC_STAMPS
+// diagnostic build only (tools/scores_stamps.py): s_memtime at the phase boundaries of each workgroup's SECOND item, wave SC_STAMP_WAVE
+__device__ uint64_t g_sc_stamps[256 * 16];
+#ifndef SC_STAMP_WAVE
+#define SC_STAMP_WAVE 0
+#endif
+#define SC_STAMP(i) { if (wave == SC_STAMP_WAVE && idx == slot + nwx) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+    if (l == 0) g_sc_stamps[(int)blockIdx.x * 16 + (i)] = t_; } }
+#else
+#define SC_STAMP(i)
+#endif
+
 template <bool BWD>
 __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,14 +118,28 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   float* stats = reinterpret_cast<float*>(smem + STATS_OFF);
 
-  const int pid = xcd_remap(blockIdx.x, g.nblk);
-  const int qt = pid % g.tiles, head = (pid / g.tiles) % g.heads, n = pid / (g.tiles * g.heads);
-  const int m0 = qt * TM;
-  const int rows = min(TM, g.Lq - m0);
-  const bf16_t* A0 = g.a + (int64_t)n * g.sa + (int64_t)m0 * g.lda + head * g.d;
-  const bf16_t* B0 = g.b + (int64_t)n * g.sb + head * g.d;
-  const i32x4 rsa = make_rsrc(A0, (uint32_t)(((int64_t)(rows - 1) * g.lda + g.d) * 2));
-  const i32x4 rsb = make_rsrc(B0, (uint32_t)(((int64_t)(g.Lk - 1) * g.ldb + g.d) * 2));
+  // Persistent: XCD x (blockIdx.x & 7) owns a contiguous range of work items -- (sequence, head, query tile), query tile fastest -- and
+  // its workgroups walk it with stride (workgroups of the XCD): at any time the XCD works on neighbouring items, so the three query
+  // tiles of a (sequence, head) read the same keys from one L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nwx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int per = g.nblk >> 3, rem = g.nblk & 7;
+  const int first = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per, count = per + (xcd < rem ? 1 : 0);
+  struct Item { int n, head, m0, rows; i32x4 rsa, rsb; };
+  auto item_of = [&](int idx) {
+    Item t;
+    const int pid = first + idx;
+    const int qt = pid % g.tiles;
+    t.head = (pid / g.tiles) % g.heads;
+    t.n = pid / (g.tiles * g.heads);
+    t.m0 = qt * TM;
+    t.rows = min(TM, g.Lq - t.m0);
+    const bf16_t* A0 = g.a + (int64_t)t.n * g.sa + (int64_t)t.m0 * g.lda + t.head * g.d;
+    const bf16_t* B0 = g.b + (int64_t)t.n * g.sb + t.head * g.d;
+    t.rsa = make_rsrc(A0, (uint32_t)(((int64_t)(t.rows - 1) * g.lda + g.d) * 2));
+    t.rsb = make_rsrc(B0, (uint32_t)(((int64_t)(g.Lk - 1) * g.ldb + g.d) * 2));
+    return t;
+  };
+  if (slot >= count) return;
 
   // DMA: one wave-instruction = 8 rows x 128 B; lane l -> row 8 gi + (l >> 3), slot l & 7 <- chunk (l & 7) ^ ((row >> 1) & 7)
   unsigned va[2], vb[6];
@@ -117,13 +153,34 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
     const int row = 8 * (wave * 6 + i) + (l >> 3);
     vb[i] = (unsigned)(row * g.ldb * 2 + (((l & 7) ^ ((row >> 1) & 7)) << 4));
   }
-#define SC_ISSUE(ST, KT)                                                                                          \
-  {                                                                                                               \
-    const unsigned sb_ = lds0 + (ST) * STAGE, so_ = (unsigned)(KT) * 128u;                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) dma16(rsa, va[i], so_, sb_ + (wave * 2 + i) * 1024);            \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) dma16(rsb, vb[i], so_, sb_ + A_BYTES + (wave * 6 + i) * 1024);  \
+#define SC_ISSUE(T, ST, KT)                                                                                          \
+  {                                                                                                                  \
+    const unsigned sb_ = lds0 + (ST) * STAGE, so_ = (unsigned)(KT) * 128u;                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) dma16<SC_NT_A>((T).rsa, va[i], so_, sb_ + (wave * 2 + i) * 1024);            \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) dma16<false>((T).rsb, vb[i], so_, sb_ + A_BYTES + (wave * 6 + i) * 1024);  \
   }
-  SC_ISSUE(0, 0)
+  const int nk = g.d / BKE;
+  const int fb0 = lr * 128 + ((lg ^ (lr >> 1)) << 4), fb1 = lr * 128 + (((lg + 4) ^ (lr >> 1)) << 4);
+  const float keep_scale = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+  const uint32_t thr = rng_threshold(g.drop_p);
+  const int gq = ((lg & 1) << 1) | (lg >> 1);  // after pair_swap this lane holds keys 8 gq .. 8 gq + 7 of a block pair
+  // vector-memory operations of one epilogue that are YOUNGER than the next item's first DMAs (issued before the epilogue): the first
+  // wait of the next K loop must not drain them
+  const bool many_stores = !BWD && g.out1 != nullptr;
+
+  // The DMA stream of this workgroup is continuous over its items: stream step q (item q / nk, K step q % nk) lands in stage q & 1 and
+  // is issued two steps ahead, as soon as every wave has read step q - 2's fragments out of that stage (two K steps of 64 in flight:
+  // one step ahead -- one 64 KiB request per 0.7 us of MFMA work -- left every K step waiting 2-3 us for its data).
+  Item cur = item_of(slot);
+  SC_ISSUE(cur, 0, 0)
+  SC_ISSUE(cur, 1, 1)
+  int gs = 0;
+  for (int idx = slot; idx < count; idx += nwx) {
+  const int n = cur.n, head = cur.head, m0 = cur.m0, rows = cur.rows;
+  const bool first_item = idx == slot, has_nxt = idx + nwx < count;
+  Item nxt = cur;
+  if (has_nxt) nxt = item_of(idx + nwx);
+  SC_STAMP(0)
 
   // validity of this lane's key columns 96 wc + 16 j + 4 lg + e as one byte each (loaded now, used in the epilogue)
   uint32_t kvw[6];
@@ -141,36 +198,48 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.d / BKE;
-  const int fb0 = lr * 128 + ((lg ^ (lr >> 1)) << 4), fb1 = lr * 128 + (((lg + 4) ^ (lr >> 1)) << 4);
-  for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of stage kt & 1 has landed
-    __syncthreads();                     // everybody's has; everybody is done reading the other stage
-    if (kt + 1 < nk) SC_ISSUE((kt + 1) & 1, kt + 1)
-    const char* As = smem + (kt & 1) * STAGE + wr * (64 * 128);
-    const char* Bs = smem + (kt & 1) * STAGE + A_BYTES + wc * (96 * 128);
+  for (int kt = 0; kt < nk; ++kt, ++gs) {
+    // This wave's share of stream step gs has landed.  Vector-memory operations retire in issue order; younger than step gs's DMAs
+    // are step gs + 1's (8 per wave, if that step exists) and, at an item's first step, the previous item's result stores (12 or 24
+    // per lane, issued whatever the bounds): leave those in flight.  (A smaller count than the true one only waits longer.)
+    if (kt == 0 && !first_item) {
+      if (many_stores) __builtin_amdgcn_s_waitcnt(0x8f70);  // vmcnt(32)
+      else __builtin_amdgcn_s_waitcnt(0x4f74);              // vmcnt(20)
+    } else if (kt + 1 < nk || has_nxt) {
+      __builtin_amdgcn_s_waitcnt(0x0f78);                   // vmcnt(8)
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
+    }
+    __syncthreads();  // everybody's share has
+    SC_STAMP(1 + kt)
+    const int st = gs & 1;
+    const char* As = smem + st * STAGE + wr * (64 * 128);
+    const char* Bs = smem + st * STAGE + A_BYTES + wc * (96 * 128);
+    bf16x8 af[2][4], bfr[2][6];
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       const int fb = kh ? fb1 : fb0;
-      bf16x8 af[4], bfr[6];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 2048 + fb);
+      for (int i = 0; i < 4; ++i) af[kh][i] = *reinterpret_cast<const bf16x8*>(As + i * 2048 + fb);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 2048 + fb);
+      for (int j = 0; j < 6; ++j) bfr[kh][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 2048 + fb);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragments are in registers
+    __syncthreads();                     // everybody's are: the stage is free for stream step gs + 2
+    if (kt + 2 < nk) SC_ISSUE(cur, st, kt + 2)
+    else if (has_nxt) SC_ISSUE(nxt, st, kt + 2 - nk)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kh][j], af[kh][i], acc[i][j], 0, 0, 0);
   }
-#undef SC_ISSUE
-
+  SC_STAMP(8)
+  SC_STAMP(9)
   // ---- epilogue.  acc[i][j][e] = score of query m0 + 64 wr + 16 i + lr, key 96 wc + 16 j + 4 lg + e -------------------------------------
   const int64_t grow0 = ((int64_t)n * g.heads + head) * g.Lq + m0;  // global row index of the tile's first query
   const uint32_t tile_bytes = (uint32_t)rows * (uint32_t)g.Lk * 2u;
-  const float keep_scale = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
-  const uint32_t thr = rng_threshold(g.drop_p);
-  const int gq = ((lg & 1) << 1) | (lg >> 1);  // after pair_swap this lane holds keys 8 gq .. 8 gq + 7 of a block pair
   uint32_t rkey[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) rkey[i] = g.drop_p > 0.f ? rng_row_key(g.seed, g.offset + (uint64_t)(grow0 + 64 * wr + 16 * i + lr)) : 0u;
@@ -212,6 +281,7 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
       if (lg == 0) *reinterpret_cast<float2*>(stats + ((64 * wr + 16 * i + lr) * 4 + wc) * 2) = make_float2(m, sum);
     }
     __syncthreads();
+    SC_STAMP(10)
     const __amdgpu_buffer_rsrc_t rp = as_rsrc(g.out0 + grow0 * g.Lk, tile_bytes);
     const __amdgpu_buffer_rsrc_t rd = as_rsrc(g.out1 ? g.out1 + grow0 * g.Lk : nullptr, g.out1 ? tile_bytes : 0u);
 #pragma unroll
@@ -234,7 +304,7 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
         uint32_t y[2] = {f32x2_to_bf16x2(v[4], v[5]), f32x2_to_bf16x2(v[6], v[7])};
         pair_swap(x, y);
         const int vo = mat_off(i, pr);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, rp, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, rp, vo, 0, SC_NT_ST);
         if (g.out1) {
           // columns 96 wc + 16 (2 pr + b) + 4 lg + e: pairs (col >> 1) and (col >> 1) + 1 of each block
 #pragma unroll
@@ -250,7 +320,7 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
           uint32_t dx[2] = {f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3])};
           uint32_t dy[2] = {f32x2_to_bf16x2(v[4], v[5]), f32x2_to_bf16x2(v[6], v[7])};
           pair_swap(dx, dy);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{dx[0], dx[1], dy[0], dy[1]}, rd, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{dx[0], dx[1], dy[0], dy[1]}, rd, vo, 0, SC_NT_ST);
         }
       }
     }
@@ -298,6 +368,7 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
       if (lg == 0) stats[(64 * wr + 16 * i + lr) * 4 + wc] = dot;
     }
     __syncthreads();
+    SC_STAMP(10)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + (64 * wr + 16 * i + lr) * 4);
@@ -316,10 +387,14 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
         uint32_t x[2] = {f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3])};
         uint32_t y[2] = {f32x2_to_bf16x2(v[4], v[5]), f32x2_to_bf16x2(v[6], v[7])};
         pair_swap(x, y);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, rs, mat_off(i, pr), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, rs, mat_off(i, pr), 0, SC_NT_ST);
       }
     }
   }
+  SC_STAMP(11)
+  cur = nxt;  // (the statistics words are next written behind the K loop's barriers)
+  }
+#undef SC_ISSUE
 }
 
 template <bool BWD>
@@ -327,20 +402,34 @@ int launch(const Args& a, hipStream_t s) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scores_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
       hipSuccess)
     return case_set_error(CASE_E_LAUNCH, "case_attention_scores: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL((scores_kernel<BWD>), dim3(a.nblk), dim3(NTHR), LDS_BYTES, s, a);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;  // whole XCD rounds; one workgroup per CU (132 KiB of LDS each)
+  hipLaunchKernelGGL((scores_kernel<BWD>), dim3(a.nblk < cus ? a.nblk : cus), dim3(NTHR), LDS_BYTES, s, a);
   return case_check_launch(BWD ? "case_attention_scores_bwd" : "case_attention_scores_fwd");
 }
 
+#ifdef SC_STAMPS
+int read_stamps(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_stamps), sizeof(g_sc_stamps)) == hipSuccess ? 0 : -1; }
+#endif
+
 bool shape_ok(const CaseAttnDesc* d) {
-  return d->head_dim > 0 && d->head_dim % BKE == 0 && d->Lk > 0 && d->Lk <= TN && d->Lk % 8 == 0 && d->Lq > 0 && !d->causal;
+  return d->head_dim >= 2 * BKE && d->head_dim % BKE == 0 && d->Lk > 0 && d->Lk <= TN && d->Lk % 8 == 0 && d->Lq > 0 && !d->causal;
 }
 
 }  // namespace attn_sc
 
+#ifdef SC_STAMPS
+extern "C" int case_attention_scores_stamps(uint64_t* out) { return attn_sc::read_stamps(out); }
+#endif
+
 extern "C" int case_attention_scores_supported(const CaseAttnDesc* d) { return d && attn_sc::shape_ok(d) ? 1 : 0; }
 
 #define CASE_SCORES_CHECKS(NAME, A, LDA, SA, B, LDB, SB)                                                                              \
-  CASE_REQUIRE(attn_sc::shape_ok(d), NAME ": needs head_dim %% 64 == 0, Lk <= 384, Lk %% 8 == 0, no causal mask");                     \
+  CASE_REQUIRE(attn_sc::shape_ok(d), NAME ": needs head_dim %% 64 == 0 and >= 128, Lk <= 384, Lk %% 8 == 0, no causal mask");                     \
   CASE_REQUIRE(d->N > 0 && d->heads > 0 && d->N * d->heads * ((d->Lq + 127) / 128) < (1ll << 31), NAME ": bad batch geometry");       \
   CASE_REQUIRE((LDA) % 8 == 0 && (LDB) % 8 == 0 && (SA) % 8 == 0 && (SB) % 8 == 0 && (uintptr_t)(A) % 16 == 0 &&                      \
                    (uintptr_t)(B) % 16 == 0,                                                                                           \

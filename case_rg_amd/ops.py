@@ -5,6 +5,7 @@ arithmetic pass over an activation is a kernel of libcase_hip.so launched throug
 stream.  There is no eager fallback: tensors must live on a ROCm device.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -618,7 +619,7 @@ def _src_key(t):
 #   "fused"   the fused kernels wherever they are built (64, 96, 320, 480: forward and backward)
 #   "unfused" never fused (tests run the production-shape fixtures under both)
 ATTENTION_MODE = "auto"
-SCORES_FUSED = True  # the GEMM + softmax + GEMM path keeps its scores in the score GEMM's accumulators where K17 covers the shape
+SCORES_FUSED = os.environ.get("CASE_SCORES_FUSED", "1") != "0"  # the GEMM + softmax + GEMM path keeps its scores in the score GEMM's accumulators where K17 covers the shape
 _FUSED_TRAINING = (64, 96)
 _FUSED_INFERENCE = (64, 96, 320)
 
@@ -734,8 +735,8 @@ class AttentionFn(Function):
 
     @staticmethod
     def _scores_fused(a_src, b_src, a_off, b_off, heads, d, Lq, Lk, causal):
-        """K17 covers this product (bf16, head_dim % 64 == 0, Lk <= 384, Lk % 8 == 0, no causal mask, 16-byte aligned slices)."""
-        if not SCORES_FUSED or a_src.dtype != torch.bfloat16 or causal or d % 64 or Lk > 384 or Lk % 8:
+        """K17 covers this product (bf16, head_dim % 64 == 0 and >= 128, Lk <= 384, Lk % 8 == 0, no causal mask, 16-byte aligned slices)."""
+        if not SCORES_FUSED or a_src.dtype != torch.bfloat16 or causal or d % 64 or d < 128 or Lk > 384 or Lk % 8:
             return False
         return all(t.shape[2] % 8 == 0 and off % 8 == 0 and t.data_ptr() % 16 == 0 for t, off in ((a_src, a_off), (b_src, b_off)))
 

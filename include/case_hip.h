@@ -210,7 +210,7 @@ int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, cons
  *     scores) + case_softmax_fwd.  Rows without a valid key give exact zeros.
  *   case_attention_scores_bwd: ds = p (g - rowsum(g p)), g = keep ? (dout v^T) / (1 - drop_p) : 0, bf16 [N, heads, Lq, Lk];
  *     replaces case_gemm (dP) + case_softmax_bwd.  dout is addressed with ldo / so, v with ldv / sv of the descriptor.
- * Scope (case_attention_scores_supported(d) != 0): bf16, head_dim a multiple of 64, Lk <= 384 and a multiple of 8, not causal. */
+ * Scope (case_attention_scores_supported(d) != 0): bf16, head_dim a multiple of 64 and >= 128, Lk <= 384 and a multiple of 8, not causal. */
 int case_attention_scores_supported(const CaseAttnDesc* d);
 int case_attention_scores_fwd(const CaseAttnDesc* d, const void* q, const void* k, const uint8_t* key_valid, void* p,
                               void* p_dropped, case_stream_t stream);
