@@ -243,7 +243,7 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[DW / 32], b
 // forward.  Workgroup = NQ blocks of 32 queries x NS head-dim slices (64 NS NQ threads).  SPLITKV: blockIdx also selects a
 // key chunk; the unnormalised partial goes to the workspace instead of O / LSE.
 // =====================================================================================================
-template <int D, int NS, int NQ, int TS, int MINW, bool SPLITKV>
+template <int D, int NS, int NQ, int TS, int MINW, bool SPLITKV, bool DROP = true>
 __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs a) {
   constexpr int NT = 64 * NS * NQ, DH = D / NS, KSW = DH / 16, OB = DH / 32, KT = TS / 32;
   static_assert(D % NS == 0 && DH % 32 == 0, "head-dim slices must be multiples of 32");
@@ -377,7 +377,9 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs
         ps += st[e];
       }
       lsum += ps;
-      if (a.drop_p > 0.f) drop_tile_rows(st, row_key, (uint32_t)key0, half, thr, keep_scale);
+      if constexpr (DROP) {  // (inference launches the DROP = false instantiation: no hash code, no register copies at the join)
+        if (a.drop_p > 0.f) drop_tile_rows(st, row_key, (uint32_t)key0, half, thr, keep_scale);
+      }
       // ---- O^T += V^T P^T  (this wave's head-dim slice)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -754,13 +756,15 @@ template <int D>
 int launch_fwd(const FaArgs& a, hipStream_t s) {
   using P = Plan<D>;
   const size_t lds = fwd_lds<D>();
-  auto kernel = &fa_fwd_kernel<D, P::NS, P::NQ, P::TS, P::MINW, false>;
+  auto kernel = &fa_fwd_kernel<D, P::NS, P::NQ, P::TS, P::MINW, false, true>;
+  auto kernel_nodrop = &fa_fwd_kernel<D, P::NS, P::NQ, P::TS, P::MINW, false, false>;
   static bool attr = false;
   if (!attr) {
     set_lds(kernel, lds);
+    set_lds(kernel_nodrop, lds);
     attr = true;
   }
-  hipLaunchKernelGGL(kernel, dim3(a.nblk), dim3(64 * P::NS * P::NQ), lds, s, a);
+  hipLaunchKernelGGL(a.drop_p > 0.f ? kernel : kernel_nodrop, dim3(a.nblk), dim3(64 * P::NS * P::NQ), lds, s, a);
   return case_check_launch("case_attention_fwd");
 }
 
