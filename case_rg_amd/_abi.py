@@ -40,6 +40,11 @@ class AttnDesc(C.Structure):
                [("causal", i32), ("scale", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
 
 
+class AttnProductDesc(C.Structure):
+    _fields_ = [(n, i64) for n in ("N", "heads", "M", "Kc", "head_dim", "lda", "sa_seq", "sa_head", "ldb", "sb_seq", "sb_head",
+                                   "ldc", "sc_seq", "sc_head")] + [("a_transposed", i32), ("alpha", f32)]
+
+
 # name -> argument types (all return int); mirrors include/case_hip.h one to one
 SIGNATURES = {
     "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
@@ -62,6 +67,8 @@ SIGNATURES = {
     "case_attention_scores_supported": [C.POINTER(AttnDesc)],
     "case_attention_scores_fwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr],
     "case_attention_scores_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr],
+    "case_attention_product_supported": [C.POINTER(AttnProductDesc)],
+    "case_attention_product": [C.POINTER(AttnProductDesc), ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],
     "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],
     "case_mask_rows": [ptr, ptr, ptr, i64, i64, i32, ptr],

@@ -412,6 +412,194 @@ int launch(const Args& a, hipStream_t s) {
   return case_check_launch(BWD ? "case_attention_scores_bwd" : "case_attention_scores_fwd");
 }
 
+// =====================================================================================================================================
+// The four products AROUND the probabilities (O = Pd V, dQ = alpha dS K, dV = Pd^T dO, dK = alpha dS^T Q) on the same skeleton: a
+// workgroup owns 128 output rows x all 320 head-dim columns of one (sequence, head), the [L, L] operand is read once, the 320-wide
+// operand (V / K / dO / Q: memory rows = the contraction index) comes in k-major pieces of [8 k-rows][64 columns] whose chunks are
+// swizzled on the source side (chunk c of k-row j of k-block kb at slot c ^ 2 f, f = ((j >> 1) & 1) + 2 (kb & 1): the scheme of
+// gemm8w.inc) and is read by ds_read_b64_tr_b16 pairs.  AK: the [L, L] operand is used transposed (dV, dK: output rows = keys,
+// contraction over the queries), so it is k-major as well.  Waves 2 (row halves) x 4 (80 columns = 5 blocks each), C^T accumulator
+// orientation (a lane holds 4 consecutive columns of one row), 16-byte stores through pair_swap (8-byte for the odd fifth block).
+// =====================================================================================================================================
+constexpr int GN = 320, G_BUNITS = 3, G_STAGE = A_BYTES + G_BUNITS * 16384, G_LDS = 2 * G_STAGE;
+
+struct GArgs {
+  const bf16_t* a;   // the [L, L] matrices, [N, heads, La, lda]: AK = false rows = output rows, AK = true rows = contraction index
+  const bf16_t* b;   // [.., Kc rows, ldb] with the head's 320 columns at b + n sb1 + head sb2
+  bf16_t* c;         // output rows at c + n sc1 + head sc2 + row ldc
+  int64_t lda, ldb, ldc, sa1, sa2, sb1, sb2, sc1, sc2;
+  int M, Kc, heads, tiles, nblk;
+  float alpha;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 frag_km(const char* p) {  // 8 consecutive k of one column: k-rows j and j + 4 of a piece
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 512));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <bool AK>
+__global__ __launch_bounds__(NTHR) void rc_gemm_kernel(const GArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, lr = l & 15, lg = l >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nwx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int per = g.nblk >> 3, rem = g.nblk & 7;
+  const int first = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per, count = per + (xcd < rem ? 1 : 0);
+  struct Item { int n, head, m0, rows; i32x4 rsa, rsb; };
+  auto item_of = [&](int idx) {
+    Item t;
+    const int pid = first + idx;
+    const int mt = pid % g.tiles;
+    t.head = (pid / g.tiles) % g.heads;
+    t.n = pid / (g.tiles * g.heads);
+    t.m0 = mt * TM;
+    t.rows = min(TM, g.M - t.m0);
+    const bf16_t* Ab = g.a + (int64_t)t.n * g.sa1 + (int64_t)t.head * g.sa2;
+    if constexpr (AK) {  // columns m0 .. of every k-row
+      t.rsa = make_rsrc(Ab + t.m0, (uint32_t)(((int64_t)(g.Kc - 1) * g.lda + t.rows) * 2));
+    } else {
+      t.rsa = make_rsrc(Ab + (int64_t)t.m0 * g.lda, (uint32_t)(((int64_t)(t.rows - 1) * g.lda + g.Kc) * 2));
+    }
+    t.rsb = make_rsrc(g.b + (int64_t)t.n * g.sb1 + (int64_t)t.head * g.sb2, (uint32_t)(((int64_t)(g.Kc - 1) * g.ldb + GN) * 2));
+    return t;
+  };
+  if (slot >= count) return;
+
+  // DMA lane offsets.  k-contiguous A: as in scores_kernel (two 8-row groups per wave).  k-major operands: the wave owns k-block `wave`
+  // of the K step; lane l -> k-row j = l >> 3, slot l & 7 <- chunk (l & 7) ^ 2 f; the 64-column pieces of a k-block differ by 128 bytes.
+  const int kj = l >> 3, kf = ((kj >> 1) & 1) + 2 * (wave & 1);
+  unsigned va[2];
+  if constexpr (AK) {
+    va[0] = (unsigned)((wave * 8 + kj) * g.lda * 2 + (((l & 7) ^ (2 * kf)) << 4));
+    va[1] = va[0] + 128u;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 8 * (wave * 2 + i) + (l >> 3);
+      va[i] = (unsigned)(row * g.lda * 2 + (((l & 7) ^ ((row >> 1) & 7)) << 4));
+    }
+  }
+  const unsigned vbk = (unsigned)((wave * 8 + kj) * g.ldb * 2 + (((l & 7) ^ (2 * kf)) << 4));
+  const unsigned a_step = AK ? (unsigned)(64 * g.lda * 2) : 128u, b_step = (unsigned)(64 * g.ldb * 2);
+#define RG_ISSUE(T, ST, KT)                                                                                              \
+  {                                                                                                                      \
+    const unsigned sb_ = lds0 + (ST) * G_STAGE, sa_ = (unsigned)(KT) * a_step, so_ = (unsigned)(KT) * b_step;            \
+    if constexpr (AK) {                                                                                                  \
+      dma16<false>((T).rsa, va[0], sa_, sb_ + wave * 1024);                                                              \
+      dma16<false>((T).rsa, va[1], sa_, sb_ + 8192 + wave * 1024);                                                       \
+    } else {                                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) dma16<SC_NT_A>((T).rsa, va[i], sa_, sb_ + (wave * 2 + i) * 1024);    \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int p = 0; p < 5; ++p)  /* pieces: unit p >> 1, column block p & 1 (columns 64 p ..) */         \
+        dma16<false>((T).rsb, vbk, so_ + p * 128u, sb_ + A_BYTES + (p >> 1) * 16384 + (p & 1) * 8192 + wave * 1024);     \
+  }
+  // fragment lane bases.  k-major block x (16 columns) of a piece pair: see gemm8w.inc Op<true>::init
+  const int tg = lg, tq = lr >> 2, tt = lr & 3, tf = (tq >> 1) + 2 * (tg & 1);
+  auto km_base = [&](int x) { return tg * 1024 + tq * 128 + ((((x ^ tf) * 2) + (tt >> 1)) << 4) + (tt & 1) * 8; };
+  int boff[5];  // the wave's column blocks 5 wc + jj: unit (c >> 3), column block ((c >> 2) & 1), sub-block c & 3
+#pragma unroll
+  for (int jj = 0; jj < 5; ++jj) {
+    const int c = 5 * wc + jj;
+    boff[jj] = A_BYTES + (c >> 3) * 16384 + ((c >> 2) & 1) * 8192 + km_base(c & 3);
+  }
+  int aoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = AK ? wr * 8192 + km_base(i) : wr * (64 * 128) + i * 2048 + lr * 128;
+  const int fb0 = (lg ^ (lr >> 1)) << 4, fb1 = ((lg + 4) ^ (lr >> 1)) << 4;  // k-contiguous A: chunk slots of the two k halves
+  const int nk = g.Kc / BKE;
+  const int gq = ((lg & 1) << 1) | (lg >> 1);
+
+  Item cur = item_of(slot);
+  RG_ISSUE(cur, 0, 0)
+  RG_ISSUE(cur, 1, 1)
+  int gs = 0;
+  for (int idx = slot; idx < count; idx += nwx) {
+    const bool first_item = idx == slot, has_nxt = idx + nwx < count;
+    Item nxt = cur;
+    if (has_nxt) nxt = item_of(idx + nwx);
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt, ++gs) {
+      // as in scores_kernel: 7 DMAs per wave and K step; 12 result stores per lane and item
+      if (kt == 0 && !first_item) __builtin_amdgcn_s_waitcnt(0x4f73);      // vmcnt(19)
+      else if (kt + 1 < nk || has_nxt) __builtin_amdgcn_s_waitcnt(0x0f77); // vmcnt(7)
+      else __builtin_amdgcn_s_waitcnt(0x0f70);                             // vmcnt(0)
+      __syncthreads();
+      const char* S = smem + (gs & 1) * G_STAGE;
+      bf16x8 af[2][4], bfr[2][5];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (AK) af[kh][i] = frag_km(S + kh * 4096 + aoff[i]);
+          else af[kh][i] = *reinterpret_cast<const bf16x8*>(S + aoff[i] + (kh ? fb1 : fb0));
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bfr[kh][j] = frag_km(S + kh * 4096 + boff[j]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      __syncthreads();
+      if (kt + 2 < nk) RG_ISSUE(cur, gs & 1, kt + 2)
+      else if (has_nxt) RG_ISSUE(nxt, gs & 1, kt + 2 - nk)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kh][j], af[kh][i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: acc[i][j][e] = C[m0 + 64 wr + 16 i + lr][80 wc + 16 j + 4 lg + e] -------------------------------------------------------
+    bf16_t* Ct = g.c + (int64_t)cur.n * g.sc1 + (int64_t)cur.head * g.sc2 + (int64_t)cur.m0 * g.ldc;
+    const __amdgpu_buffer_rsrc_t rc = as_rsrc(Ct, (uint32_t)(((int64_t)(cur.rows - 1) * g.ldc + GN) * 2));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rowb = (64 * wr + 16 * i + lr) * (int)g.ldc;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        uint32_t x[2] = {f32x2_to_bf16x2(acc[i][2 * pr][0] * g.alpha, acc[i][2 * pr][1] * g.alpha),
+                         f32x2_to_bf16x2(acc[i][2 * pr][2] * g.alpha, acc[i][2 * pr][3] * g.alpha)};
+        uint32_t y[2] = {f32x2_to_bf16x2(acc[i][2 * pr + 1][0] * g.alpha, acc[i][2 * pr + 1][1] * g.alpha),
+                         f32x2_to_bf16x2(acc[i][2 * pr + 1][2] * g.alpha, acc[i][2 * pr + 1][3] * g.alpha)};
+        pair_swap(x, y);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, rc, (rowb + 80 * wc + 32 * pr + 8 * gq) * 2, 0, 0);
+      }
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+      const u32x2 z = {f32x2_to_bf16x2(acc[i][4][0] * g.alpha, acc[i][4][1] * g.alpha),
+                       f32x2_to_bf16x2(acc[i][4][2] * g.alpha, acc[i][4][3] * g.alpha)};
+      __builtin_amdgcn_raw_buffer_store_b64(z, rc, (rowb + 80 * wc + 64 + 4 * lg) * 2, 0, 0);
+    }
+    cur = nxt;
+  }
+#undef RG_ISSUE
+}
+
+template <bool AK>
+int launch_rc(const GArgs& a, hipStream_t s) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rc_gemm_kernel<AK>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
+    return case_set_error(CASE_E_LAUNCH, "case_attention_product: cannot raise the dynamic LDS limit");
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+  hipLaunchKernelGGL((rc_gemm_kernel<AK>), dim3(a.nblk < cus ? a.nblk : cus), dim3(NTHR), G_LDS, s, a);
+  return case_check_launch("case_attention_product");
+}
+
 #ifdef SC_STAMPS
 int read_stamps(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_stamps), sizeof(g_sc_stamps)) == hipSuccess ? 0 : -1; }
 #endif
@@ -469,4 +657,33 @@ extern "C" int case_attention_scores_bwd(const CaseAttnDesc* d, const void* dout
   a.a = (const bf16_t*)dout; a.b = (const bf16_t*)v; a.lda = d->ldo; a.ldb = d->ldv; a.sa = d->so; a.sb = d->sv;
   a.p_in = (const bf16_t*)p; a.out0 = (bf16_t*)ds;
   return attn_sc::launch<true>(a, (hipStream_t)stream);
+}
+
+// ---- the products around the probabilities -------------------------------------------------------------------------------------------------
+static bool product_ok(const CaseAttnProductDesc* d) {
+  return d->head_dim == attn_sc::GN && d->Kc >= 2 * attn_sc::BKE && d->Kc % attn_sc::BKE == 0 && d->M > 0 && d->N > 0 && d->heads > 0;
+}
+extern "C" int case_attention_product_supported(const CaseAttnProductDesc* d) { return d && product_ok(d) ? 1 : 0; }
+
+extern "C" int case_attention_product(const CaseAttnProductDesc* d, const void* a, const void* b, void* c, case_stream_t stream) {
+  CASE_REQUIRE(d && a && b && c, "case_attention_product: null argument");
+  CASE_REQUIRE(product_ok(d), "case_attention_product: needs head_dim 320 and a contraction length that is a multiple of 64, >= 128");
+  CASE_REQUIRE(d->N * d->heads * ((d->M + 127) / 128) < (1ll << 31), "case_attention_product: bad batch geometry");
+  CASE_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0 && d->sa_seq % 8 == 0 && d->sa_head % 8 == 0 && d->sb_seq % 8 == 0 &&
+                   d->sb_head % 8 == 0 && d->sc_seq % 8 == 0 && d->sc_head % 8 == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 &&
+                   (uintptr_t)c % 16 == 0,
+               "case_attention_product: operands must be 16-byte aligned with strides that are multiples of 8 elements");
+  CASE_REQUIRE(d->lda >= (d->a_transposed ? d->M : d->Kc), "case_attention_product: lda shorter than a row of a");
+  const int64_t a_rows = d->a_transposed ? d->Kc : d->M;
+  CASE_REQUIRE(a_rows * d->lda * 2 < (1ll << 31) && d->Kc * d->ldb * 2 < (1ll << 31) && (d->M + 127) * d->ldc * 2 < (1ll << 31),
+               "case_attention_product: a sequence does not fit 32-bit buffer offsets");
+  attn_sc::GArgs g = {};
+  g.a = (const bf16_t*)a; g.b = (const bf16_t*)b; g.c = (bf16_t*)c;
+  g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+  g.sa1 = d->sa_seq; g.sa2 = d->sa_head; g.sb1 = d->sb_seq; g.sb2 = d->sb_head; g.sc1 = d->sc_seq; g.sc2 = d->sc_head;
+  g.M = (int)d->M; g.Kc = (int)d->Kc; g.heads = (int)d->heads;
+  g.tiles = (int)((d->M + 127) / 128);
+  g.nblk = g.tiles * g.heads * (int)d->N;
+  g.alpha = d->alpha;
+  return d->a_transposed ? attn_sc::launch_rc<true>(g, (hipStream_t)stream) : attn_sc::launch_rc<false>(g, (hipStream_t)stream);
 }

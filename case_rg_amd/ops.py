@@ -696,8 +696,9 @@ class AttentionFn(Function):
             ctx.save_for_backward(q_src, k_src, v_src, key_valid, O, lse)
         else:
             S, Pd = AttentionFn._probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha)
-            gemm(Pd, v_src, O, Lq, d, Lk, Lk, v_src.shape[2], E, b_off=v_off, b_kmajor=True, batch1=N, batch2=heads,
-                 sa=(heads * Lq * Lk, Lq * Lk), sb=(Lk * v_src.shape[2], d), sc=(Lq * E, d))
+            if not AttentionFn._product(Pd, v_src, v_off, O, 0, heads, d, Lq, Lk, False):
+                gemm(Pd, v_src, O, Lq, d, Lk, Lk, v_src.shape[2], E, b_off=v_off, b_kmajor=True, batch1=N, batch2=heads,
+                     sa=(heads * Lq * Lk, Lq * Lk), sb=(Lk * v_src.shape[2], d), sc=(Lq * E, d))
             ctx.save_for_backward(q_src, k_src, v_src, key_valid, S, Pd if drop is not None else None)
         ctx.meta = (q_off, k_off, v_off, heads, d, causal, drop, alpha, fused)
         return O
@@ -739,6 +740,25 @@ class AttentionFn(Function):
         if not SCORES_FUSED or a_src.dtype != torch.bfloat16 or causal or d % 64 or d < 128 or Lk > 384 or Lk % 8:
             return False
         return all(t.shape[2] % 8 == 0 and off % 8 == 0 and t.data_ptr() % 16 == 0 for t, off in ((a_src, a_off), (b_src, b_off)))
+
+    @staticmethod
+    def _product(mat, b_src, b_off, out, c_off, heads, d, M, Kc, transposed, alpha=1.0):
+        """out[n, row, head, :] = alpha * sum_k A[n, head][row, k] b[n, k, head, :], A = mat [N, heads, La, Lb] or its transpose (K17's
+        row-complete product kernel at head_dim 320); False when the shape is outside its scope (the caller runs case_gemm)."""
+        if not SCORES_FUSED or d != 320 or mat.dtype != torch.bfloat16 or Kc % 64 or Kc < 128:
+            return False
+        for t, off in ((b_src, b_off), (out, c_off)):
+            if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:
+                return False
+        N, _, La, Lb = mat.shape
+        pd = A.AttnProductDesc()
+        pd.N, pd.heads, pd.M, pd.Kc, pd.head_dim = N, heads, M, Kc, d
+        pd.lda, pd.sa_seq, pd.sa_head = Lb, heads * La * Lb, La * Lb
+        pd.ldb, pd.sb_seq, pd.sb_head = b_src.shape[2], b_src.shape[1] * b_src.shape[2], d
+        pd.ldc, pd.sc_seq, pd.sc_head = out.shape[2], out.shape[1] * out.shape[2], d
+        pd.a_transposed, pd.alpha = int(transposed), alpha
+        A.call("case_attention_product", pd, _ptr(mat), _ptr(b_src, b_off), _ptr(out, c_off), _stream())
+        return True
 
     @staticmethod
     def _probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha):
@@ -796,8 +816,9 @@ class AttentionFn(Function):
 
         gq, gk, gv = grad_of(q_src), grad_of(k_src), grad_of(v_src)
         # dV = Pd^T dO
-        gemm(Pd, dO, gv, Lk, d, Lq, Lk, E, Wv, c_off=v_off, a_kmajor=True, b_kmajor=True, batch1=N, batch2=heads,
-             sa=pstr, sb=(Lq * E, d), sc=(Lk * Wv, d))
+        if not AttentionFn._product(Pd, dO, 0, gv, v_off, heads, d, Lk, Lq, True):
+            gemm(Pd, dO, gv, Lk, d, Lq, Lk, E, Wv, c_off=v_off, a_kmajor=True, b_kmajor=True, batch1=N, batch2=heads,
+                 sa=pstr, sb=(Lq * E, d), sc=(Lk * Wv, d))
         dP = torch.empty(N, heads, Lq, Lk, dtype=dt, device=dev)
         if AttentionFn._scores_fused(dO, v_src, 0, v_off, heads, d, Lq, Lk, causal):
             # K17: dS = softmax'(dO V^T) with the row sums in the GEMM's epilogue (dP itself is never written)
@@ -810,10 +831,12 @@ class AttentionFn(Function):
             sd = _softmax_desc(N, heads, Lq, Lk, causal, _DT[dt], _DT[dt], drop)
             A.call("case_softmax_bwd", sd, _ptr(dP), _ptr(P), _ptr(dP), _stream())
         # dQ = alpha dS K ; dK = alpha dS^T Q
-        gemm(dP, k_src, gq, Lq, d, Lk, Lk, Wk, Wq, b_off=k_off, c_off=q_off, b_kmajor=True, batch1=N, batch2=heads,
-             sa=pstr, sb=(Lk * Wk, d), sc=(Lq * Wq, d), alpha=alpha)
-        gemm(dP, q_src, gk, Lk, d, Lq, Lk, Wq, Wk, b_off=q_off, c_off=k_off, a_kmajor=True, b_kmajor=True, batch1=N,
-             batch2=heads, sa=pstr, sb=(Lq * Wq, d), sc=(Lk * Wk, d), alpha=alpha)
+        if not AttentionFn._product(dP, k_src, k_off, gq, q_off, heads, d, Lq, Lk, False, alpha):
+            gemm(dP, k_src, gq, Lq, d, Lk, Lk, Wk, Wq, b_off=k_off, c_off=q_off, b_kmajor=True, batch1=N, batch2=heads,
+                 sa=pstr, sb=(Lk * Wk, d), sc=(Lq * Wq, d), alpha=alpha)
+        if not AttentionFn._product(dP, q_src, q_off, gk, k_off, heads, d, Lk, Lq, True, alpha):
+            gemm(dP, q_src, gk, Lk, d, Lq, Lk, Wq, Wk, b_off=q_off, c_off=k_off, a_kmajor=True, b_kmajor=True, batch1=N,
+                 batch2=heads, sa=pstr, sb=(Lq * Wq, d), sc=(Lk * Wk, d), alpha=alpha)
         out, seen = [], set()
         for src in (q_src, k_src, v_src):
             key = _src_key(src)

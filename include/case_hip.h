@@ -216,6 +216,22 @@ int case_attention_scores_fwd(const CaseAttnDesc* d, const void* q, const void* 
                               void* p_dropped, case_stream_t stream);
 int case_attention_scores_bwd(const CaseAttnDesc* d, const void* dout, const void* v, const void* p, void* ds,
                               case_stream_t stream);
+/* The four batched products around those probabilities at head_dim 320 (F.multi_head_attention_forward's second bmm and the three
+ * bmm of its backward): c[n, row, head, 0..319] = alpha * sum_k A[n, head][row, k] * b[n, k, head, 0..319], where A is the [L, L] matrix a
+ * (a_transposed = 0: O = Pd V, dQ = alpha dS K) or its transpose (a_transposed = 1: dV = Pd^T dO, dK = alpha dS^T Q).  Element
+ * (n, head, r, col) of a at a[n sa_seq + head sa_head + r lda + col]; k-row k of b at b[n sb_seq + head sb_head + k ldb + 0..319];
+ * output row at c[n sc_seq + head sc_head + row ldc + 0..319].  M output rows, Kc = contraction length (a multiple of 64, >= 128).
+ * One workgroup owns 128 rows x all 320 columns (a is read once); replaces case_gemm's batched 128x128 tiling for these shapes. */
+typedef struct {
+  int64_t N, heads, M, Kc, head_dim;
+  int64_t lda, sa_seq, sa_head;
+  int64_t ldb, sb_seq, sb_head;
+  int64_t ldc, sc_seq, sc_head;
+  int32_t a_transposed;
+  float alpha;
+} CaseAttnProductDesc;
+int case_attention_product_supported(const CaseAttnProductDesc* d);
+int case_attention_product(const CaseAttnProductDesc* d, const void* a, const void* b, void* c, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * elementwise / small reductions

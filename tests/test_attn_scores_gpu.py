@@ -133,7 +133,37 @@ def test_attention_op_uses_the_scores_kernels_and_agrees_with_the_two_kernel_pat
         ops.ATTENTION_MODE = prev_mode
     (o1, g1, c1), (o0, g0, c0) = res[True], res[False]
     assert c1.get("case_attention_scores_fwd") == 1 and c1.get("case_attention_scores_bwd") == 1
-    assert "case_softmax_fwd" not in c1 and "case_softmax_bwd" not in c1 and c1.get("case_gemm", 0) == c0.get("case_gemm", 0) - 2
+    assert "case_softmax_fwd" not in c1 and "case_softmax_bwd" not in c1 and c1.get("case_attention_product") == 4
+    assert c1.get("case_gemm", 0) == c0.get("case_gemm", 0) - 6 == 0  # two score GEMMs and the four products around them
     assert "case_attention_scores_fwd" not in c0 and c0.get("case_softmax_fwd") == 1
     assert (o1 - o0).norm() / o0.norm() < 5e-3
     assert (g1 - g0).norm() / g0.norm() < 2e-2  # the two-kernel path rounds dP to bf16, K17 keeps it in f32
+
+
+@pytest.mark.parametrize("N,heads,La,Lb,transposed,alpha", [
+    (2, 8, 384, 384, False, 1.0),      # O = Pd V at the cfg 2 block geometry
+    (2, 8, 384, 384, True, 0.25),      # dK = alpha dS^T Q
+    (3, 2, 200, 256, False, 0.5),      # a partial row tile (200 rows), contraction over 256
+    (3, 2, 192, 136, True, 1.0),       # transposed: 136 output rows (a partial tile), contraction over 192
+    (1, 1, 128, 128, True, 1.0),
+])
+def test_attention_product_kernel_against_f32_matmul(N, heads, La, Lb, transposed, alpha):
+    """case_attention_product (the four bmm around the probabilities at head_dim 320): c = alpha A b with A = mat or mat^T, strided
+    packed operands as the attention op passes them, rows beyond M untouched."""
+    from case_rg_amd import ops
+    d, E = 320, heads * 320
+    g = torch.Generator().manual_seed(La * 7 + Lb)
+    mat = torch.rand(N, heads, La, Lb, generator=g).to(torch.bfloat16).to(DEV)
+    M, Kc = (Lb, La) if transposed else (La, Lb)
+    b_src = (torch.randn(N, Kc, 3 * E, generator=g) * 0.5).to(torch.bfloat16).to(DEV)   # the operand sits in a packed projection
+    out = torch.full((N, M, 2 * E), 7.0, dtype=torch.bfloat16, device=DEV)
+    b_off, c_off = 2 * E, E
+    assert ops.AttentionFn._product(mat, b_src, b_off, out, c_off, heads, d, M, Kc, transposed, alpha)
+    A32 = mat.float().transpose(-1, -2) if transposed else mat.float()
+    B32 = b_src[:, :, b_off:b_off + E].reshape(N, Kc, heads, d).permute(0, 2, 1, 3).float()
+    want = alpha * (A32 @ B32)                                    # [N, heads, M, d]
+    got = out[:, :, c_off:c_off + E].reshape(N, M, heads, d).permute(0, 2, 1, 3).float()
+    err = (got - want).abs().max().item()
+    assert err <= 2.0 ** -8 * want.abs().max().item() + 1e-3, err
+    assert ((got - want).norm() / want.norm()).item() < 3e-3
+    assert (out[:, :, :c_off] == 7.0).all() and (out[:, :, c_off + E:] == 7.0).all()   # neighbouring columns untouched

@@ -58,7 +58,29 @@ def bwd_old():
     A.call("case_softmax_bwd", sd, ops._ptr(dS), ops._ptr(P), ops._ptr(dS), ops._stream())
 
 
-for name, fn in (("fwd_two_kernels", fwd_old), ("fwd_k17", fwd_new), ("bwd_two_kernels", bwd_old), ("bwd_k17", bwd_new)):
+O = torch.empty(N, L, E, dtype=torch.bfloat16, device="cuda")
+G3 = torch.empty(N, L, 3 * E, dtype=torch.bfloat16, device="cuda")
+pstr = (h * L * L, L * L)
+
+
+def pv_new():
+    assert ops.AttentionFn._product(Pd, qkv, 2 * E, O, 0, h, d, L, L, False)
+
+
+def pv_old():
+    ops.gemm(Pd, qkv, O, L, d, L, L, 3 * E, E, b_off=2 * E, b_kmajor=True, batch1=N, batch2=h, sa=pstr, sb=(L * 3 * E, d), sc=(L * E, d))
+
+
+def dv_new():
+    assert ops.AttentionFn._product(Pd, dO, 0, G3, 2 * E, h, d, L, L, True)
+
+
+def dv_old():
+    ops.gemm(Pd, dO, G3, L, d, L, L, E, 3 * E, c_off=2 * E, a_kmajor=True, b_kmajor=True, batch1=N, batch2=h, sa=pstr, sb=(L * E, d),
+             sc=(L * 3 * E, d))
+
+
+for name, fn in (("pv_gemm128", pv_old), ("pv_k17", pv_new), ("dv_gemm128", dv_old), ("dv_k17", dv_new), ("fwd_two_kernels", fwd_old), ("fwd_k17", fwd_new), ("bwd_two_kernels", bwd_old), ("bwd_k17", bwd_new)):
     ms = timeit(fn)
     print(json.dumps({"case": name, "N": N, "heads": h, "L": L, "head_dim": d, "p_drop": 0.1, "ms": round(ms, 4),
                       "gemm_tflops": round(flops / ms / 1e9, 1)}))
