@@ -34,6 +34,9 @@ def family(name):
     m = re.search(r"chain_kernel<(\d)>", name)
     if m:
         return "chain_kernel<%s>" % {"0": "full", "1": "tail", "2": "head"}.get(m.group(1), m.group(1))
+    m = re.search(r"(scores_kernel<(?:true|false)>|rc_gemm_kernel<(?:true|false)>)", name)
+    if m:
+        return m.group(1)
     m = re.search(r"(attn_decode\w*|fa_fwd\w*_kernel|fa_bwd\w*_kernel)", name)
     if m:
         return m.group(1)

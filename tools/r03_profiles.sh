@@ -1,7 +1,8 @@
+# Round-3 evidence run (GPU box): bash tools/r03_profiles.sh  -> gpurun_out/r03z/*  (copy what is judged into profiles/r03_*)
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-O=$R/gpurun_out/r03r
+O=$R/gpurun_out/r03z
 mkdir -p $O
 cd $R
 # 1. the default bench command under kernel-trace stats
@@ -21,7 +22,15 @@ python3 tools/pmc_traffic.py $(find $O/pmc_f -name 'f_counter_collection.csv') $
 python3 tools/mfma_util.py $(find $O/pmc_m -name 'm_counter_collection.csv') $O/mfma_util_step.json > $O/mfma_util.txt
 cp $(find $O/stats -name 's_kernel_stats.csv') $O/bench_kernel_stats.csv
 cp $(find $O/enc -name 'e_kernel_stats.csv') $O/enc_kernel_stats.csv
-# keep the merge small: drop the raw traces
 rm -rf $O/stats $O/enc $O/pmc_f $O/pmc_w $O/pmc_m
-python3 tools/chain_stamps.py > $O/chain_stamps.txt 2>&1 || true
+# 4. the other modes and the micro-benchmarks
+python3 bench.py --mode decode --batch 256 > $O/dec.json 2> $O/dec.err
+python3 bench.py --mode decode --batch 256 --graph --no-cpu-baseline > $O/dec_graph.json 2> $O/dec_graph.err
+python3 bench.py --model masque --no-cpu-baseline --no-north-star > $O/masque.json 2> $O/masque.err
+python3 bench.py --mode cfg5 --no-cpu-baseline > $O/cfg5.json 2> $O/cfg5.err
+python3 bench.py --mode encoder --batch 64 --enc-layers 3 > $O/enc3.json 2> $O/enc3.err
+python3 bench.py --mode encoder --batch 64 > $O/enc6.json 2> $O/enc6.err
+python3 tools/scores_bench.py > $O/scores_bench.jsonl 2> $O/scores_bench.err
+python3 tools/attn_bench.py > $O/attn_bench.jsonl 2> $O/attn_bench.err
+python3 tools/chain_bench.py > $O/chain_bench.jsonl 2> $O/chain_bench.err
 ls -la $O
