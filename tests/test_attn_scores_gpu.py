@@ -42,6 +42,7 @@ def _desc(ops, N, heads, Lq, Lk, d, q_src, k_src, v_src, drop):
 
 @pytest.mark.parametrize("N,heads,Lq,Lk,d,p_drop,packed", [
     (3, 8, 384, 384, 320, 0.1, True),     # the cfg 2 block geometry
+    (30, 8, 384, 384, 320, 0.1, True),    # 720 work items on 256 persistent workgroups: the DMA stream crosses item boundaries
     (3, 8, 384, 384, 320, 0.0, True),
     (4, 2, 100, 200, 128, 0.1, False),    # ragged: a partial query tile, key quarters that end early / are empty
     (3, 3, 130, 8, 128, 0.25, False),     # one key block only
@@ -142,6 +143,8 @@ def test_attention_op_uses_the_scores_kernels_and_agrees_with_the_two_kernel_pat
 
 @pytest.mark.parametrize("N,heads,La,Lb,transposed,alpha", [
     (2, 8, 384, 384, False, 1.0),      # O = Pd V at the cfg 2 block geometry
+    (30, 8, 384, 384, False, 0.5),     # 720 work items on 256 persistent workgroups (two to three items each)
+    (30, 8, 384, 384, True, 1.0),
     (2, 8, 384, 384, True, 0.25),      # dK = alpha dS^T Q
     (3, 2, 200, 256, False, 0.5),      # a partial row tile (200 rows), contraction over 256
     (3, 2, 192, 136, True, 1.0),       # transposed: 136 output rows (a partial tile), contraction over 192
@@ -167,3 +170,36 @@ def test_attention_product_kernel_against_f32_matmul(N, heads, La, Lb, transpose
     assert err <= 2.0 ** -8 * want.abs().max().item() + 1e-3, err
     assert ((got - want).norm() / want.norm()).item() < 3e-3
     assert (out[:, :, :c_off] == 7.0).all() and (out[:, :, c_off + E:] == 7.0).all()   # neighbouring columns untouched
+
+
+def test_scores_and_products_are_bit_reproducible_across_launch_geometries():
+    """No atomics anywhere in K17: the same (sequence, head) must give the same bits whether its work items are the only ones of a
+    launch (one item per workgroup) or ride in the middle of a persistent workgroup's stream (race screen for the cross-item prefetch)."""
+    from case_rg_amd import _abi as A, ops
+    N, heads, L, d = 40, 8, 384, 320
+    E = heads * d
+    (qkv, _, _, q_off, k_off, v_off), valid, dO = _inputs(N, heads, L, L, d, 91, True)
+    kv8 = valid.to(torch.uint8)
+    drop = (0.1, 4321, 10)
+
+    def run(sl):
+        q = qkv[sl].contiguous()
+        n = q.shape[0]
+        ad = _desc(ops, n, heads, L, L, d, q, q, q, drop)
+        P, Pd, dS = (torch.empty(n, heads, L, L, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+        O = torch.empty(n, L, E, dtype=torch.bfloat16, device=DEV)
+        G = torch.zeros(n, L, 3 * E, dtype=torch.bfloat16, device=DEV)
+        A.call("case_attention_scores_fwd", ad, ops._ptr(q, q_off), ops._ptr(q, k_off), ops._ptr(kv8[sl].contiguous()), ops._ptr(P), ops._ptr(Pd),
+               ops._stream())
+        A.call("case_attention_scores_bwd", ad, ops._ptr(dO[sl].contiguous()), ops._ptr(q, v_off), ops._ptr(P), ops._ptr(dS), ops._stream())
+        assert ops.AttentionFn._product(Pd, q, v_off, O, 0, heads, d, L, L, False)
+        assert ops.AttentionFn._product(dS, q, q_off, G, k_off, heads, d, L, L, True, 0.5)
+        return P, Pd, dS, O, G
+
+    # NOTE: the dropout row keys depend on the global row index, so a slice is compared with the same rows of the full launch only
+    # for the first sequences (offset 0): run the full batch twice and the leading two sequences alone
+    full1, full2, head2 = run(slice(0, N)), run(slice(0, N)), run(slice(0, 2))
+    for a, b in zip(full1, full2):
+        assert torch.equal(a, b)
+    for a, b in zip(full1, head2):
+        assert torch.equal(a[:2], b)
