@@ -188,7 +188,10 @@ class CaSE(nn.Module):
         return to_sentence(batch_indices, self.id2vocab)
 
     def _encode_select_extract(self, data):
-        eq, ep = self.query_encoder(data['query']), self.passage_encoder(data['passage'])
+        if self.query_encoder is self.passage_encoder:  # one shared encoder (reference :262-263): both inputs in one pass
+            eq, ep = self.query_encoder.forward_many([data['query'], data['passage']])
+        else:
+            eq, ep = self.query_encoder(data['query']), self.passage_encoder(data['passage'])
         ps = self.passage_selection.action(data['query'], data['passage'], encode_query=eq, encode_passage=ep)
         se = self.span_extraction.action(data['query'], data['passage'], encode_query=eq, encode_passage=ep,
                                          passage_selection_result=ps)

@@ -139,8 +139,12 @@ class Masque(nn.Module):
         return to_sentence(batch_indices, self.id2vocab)
 
     def _encode_select(self, data):
-        eq = self.query_encoder(data['query'])[0][:, :, -1]
-        ep = self.passage_encoder(data['passage'])[0][:, :, -1]
+        if self.query_encoder is self.passage_encoder:  # one shared encoder (reference :207-208): both inputs in one pass
+            oq, op = self.query_encoder.forward_many([data['query'], data['passage']])
+            eq, ep = oq[0][:, :, -1], op[0][:, :, -1]
+        else:
+            eq = self.query_encoder(data['query'])[0][:, :, -1]
+            ep = self.passage_encoder(data['passage'])[0][:, :, -1]
         return eq, ep, self.passage_selection.action(data['query'], data['passage'], encode_query=eq, encode_passage=ep)
 
     def do_train(self, data):

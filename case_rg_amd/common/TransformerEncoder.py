@@ -44,6 +44,22 @@ class TransformerEncoderLayer(nn.Module):
         return ops.ffn(s, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                        self.activation, p_inner=p, p_out=p, residual=s)
 
+    def forward_rows(self, x, groups, valids):
+        """The same layer over SEVERAL sequence groups at once: x [rows, E] holds the rows of all groups back to back
+        (``groups`` = [(first row, sequences, length)]); everything row-local runs once, the attention core once per group."""
+        p = config.drop_p(self.p, self.training)
+        at = self.self_attn
+        s = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if torch.is_grad_enabled() and s.requires_grad:
+            qkv, res = ops.linear_carry(s, at.in_proj_weight, at.in_proj_bias)
+        else:
+            qkv, res = ops.linear(s, at.in_proj_weight, at.in_proj_bias), s
+        ctx = ops.attention_groups(qkv, groups, valids, at.num_heads, at.head_dim, p_drop=config.drop_p(at.dropout, self.training))
+        s = ops.linear(ctx, at.out_proj.weight, at.out_proj.bias, residual=res, p_drop=config.drop_p(self.p, self.training))
+        s = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return ops.ffn(s, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                       self.activation, p_inner=p, p_out=p, residual=s)
+
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
         """src [L, N, E] (sequence first, as the reference); src_key_padding_mask [N, L] True = pad."""
         valid = None if src_key_padding_mask is None else ~src_key_padding_mask
@@ -82,6 +98,18 @@ class TransformerEncoder(nn.Module):
         else:
             for layer in self.layers:
                 x = layer.forward_batch_first(x, valid, causal)
+        if self.norm is not None:
+            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+    def rows_supported(self, dtype, needs_grad):
+        at = self.layers[0].self_attn
+        return ops.attention_groups_supported(dtype, at.num_heads, at.head_dim, 3 * at.embed_dim, needs_grad)
+
+    def forward_rows(self, x, groups, valids):
+        """x [rows, E]: several sequence groups back to back (see TransformerEncoderLayer.forward_rows)."""
+        for layer in self.layers:
+            x = layer.forward_rows(x, groups, valids)
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x

@@ -10,6 +10,8 @@ Differences from the reference that do not change results:
   * greedy decoding keeps the reference's step semantics (argmax of the last position, lowest index on ties, fixed
     T steps) but projects each memory's K/V and additive-attention keys once instead of once per step.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +23,7 @@ from .TransformerEncoder import TransformerEncoder, TransformerEncoderLayer
 from .Utils import generate_square_subsequent_mask
 
 _generate_square_subsequent_mask = generate_square_subsequent_mask
+MERGED_ENCODE = os.environ.get("CASE_MERGED_ENCODE", "1") != "0"  # A/B switch of TransformerSeqEncoder.forward_many
 
 
 def _embedding(vocab, width, max_len=1000, emb_matrix=None):
@@ -60,6 +63,35 @@ class TransformerSeqEncoder(nn.Module):
         y = self.enc.forward_batch_first(x, valid)
         state = ops.masked_mean(y, valid)
         return y.reshape(B, N, L, -1).unsqueeze(2), state.reshape(B, N, -1).unsqueeze(2)
+
+
+    def forward_many(self, id_tensors):
+        """Several inputs through the SAME encoder in one pass (the reference's models share one encoder between query and passages:
+        CaSE/Model.py:262-263, Masque/Model.py:207-208): embeddings of all inputs back to back in one [rows, H] buffer, every
+        row-local op of every layer launched once, the attention core once per input.  Returns what ``forward`` returns, per input;
+        the training path's ~120 launches on the 2048 query rows ride along with the 122 880 passage rows, and the shared
+        parameters receive ONE gradient instead of two that autograd adds.  Falls back to separate passes where the grouped attention
+        does not apply (f32 parity mode, the inference chain, unfused mode)."""
+        dt = config.compute_dtype()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if (not MERGED_ENCODE or len(id_tensors) < 2 or not needs_grad or not self.enc.rows_supported(dt, needs_grad)
+                or not all(t.is_cuda for t in id_tensors)):
+            return [self.forward(t) for t in id_tensors]
+        xs, groups, valids, shapes, r0 = [], [], [], [], 0
+        for t in id_tensors:
+            B, N, L = t.shape
+            ids = t.reshape(B * N, L)
+            xs.append(_embed(self.embedding, ids, self.training).reshape(B * N * L, -1))
+            groups.append((r0, B * N, L))
+            valids.append(ids.ne(0))
+            shapes.append((B, N, L))
+            r0 += B * N * L
+        y = self.enc.forward_rows(torch.cat(xs, dim=0), groups, valids)
+        outs = []
+        for yi, valid, (B, N, L) in zip(ops.split_rows(y, groups), valids, shapes):
+            state = ops.masked_mean(yi, valid)
+            outs.append((yi.reshape(B, N, L, -1).unsqueeze(2), state.reshape(B, N, -1).unsqueeze(2)))
+        return outs
 
 
 class PointerDecoderCore(nn.Module):

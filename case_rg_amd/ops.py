@@ -849,6 +849,89 @@ def attention(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid=None
     return AttentionFn.apply(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, _u8(key_valid), causal, p_drop)
 
 
+class AttentionGroupsFn(Function):
+    """Fused self-attention of several sequence GROUPS that live in ONE packed projection buffer: rows [r0, r0 + N L) of qkv [rows, 3E]
+    are the N sequences of length L of a group (the shared query / passage encoder runs its row-local work -- LayerNorm, projections,
+    feed-forward -- once over the query rows and the passage rows together; only the attention core needs the sequence geometry).
+    One launch of the fused kernels per group, reading and writing slices of the shared buffers in place: no split / concat copies."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, d, p_drop, groups, *valids):
+        rows, W = qkv.shape
+        E = heads * d
+        alpha = 1.0 / math.sqrt(d)
+        O = torch.empty(rows, E, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(sum(N * heads * L for _, N, L in groups), dtype=torch.float32, device=qkv.device)
+        drops, lo = [], 0
+        for (r0, N, L), valid in zip(groups, valids):
+            drop = (p_drop,) + config.next_rng(N * heads * L * L) if p_drop > 0.0 else None
+            view = qkv[r0:r0 + N * L].view(N, L, W)
+            ad = _attn_desc(N, heads, L, L, d, view, view, view, False, alpha, drop)
+            A.call("case_attention_fwd", ad, _ptr(qkv, r0 * W), _ptr(qkv, r0 * W + E), _ptr(qkv, r0 * W + 2 * E), _ptr(valid),
+                   _ptr(O, r0 * E), _ptr(lse, lo), _stream())
+            drops.append(drop)
+            lo += N * heads * L
+        ctx.save_for_backward(qkv, O, lse, *valids)
+        ctx.meta = (heads, d, groups, drops, alpha)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, O, lse = ctx.saved_tensors[:3]
+        valids = ctx.saved_tensors[3:]
+        heads, d, groups, drops, alpha = ctx.meta
+        rows, W = qkv.shape
+        E = heads * d
+        dO = dO if dO.is_contiguous() else dO.contiguous()
+        dqkv = torch.empty_like(qkv)  # the q, k and v slices of every row are written by the kernels
+        delta = torch.empty_like(lse)
+        lo = 0
+        for (r0, N, L), valid, drop in zip(groups, valids, drops):
+            view = qkv[r0:r0 + N * L].view(N, L, W)
+            ad = _attn_desc(N, heads, L, L, d, view, view, view, False, alpha, drop)
+            A.call("case_attention_bwd", ad, _ptr(qkv, r0 * W), _ptr(qkv, r0 * W + E), _ptr(qkv, r0 * W + 2 * E), _ptr(valid),
+                   _ptr(O, r0 * E), _ptr(lse, lo), _ptr(dO, r0 * E), _ptr(delta, lo), _ptr(dqkv, r0 * W), _ptr(dqkv, r0 * W + E),
+                   _ptr(dqkv, r0 * W + 2 * E), _stream())
+            lo += N * heads * L
+        return (dqkv, None, None, None, None) + (None,) * len(valids)
+
+
+def attention_groups_supported(dtype, heads, d, width, needs_grad):
+    """The grouped form exists for the fused kernels only (bf16, a built head size on the training / inference list, packed width 3E)."""
+    if ATTENTION_MODE == "unfused" or dtype != torch.bfloat16 or width != 3 * heads * d or width % 8:
+        return False
+    if not A.lib.case_attention_supported(d) or (needs_grad and not A.lib.case_attention_bwd_supported(d)):
+        return False
+    return ATTENTION_MODE == "fused" or d in (_FUSED_TRAINING if needs_grad else _FUSED_INFERENCE)
+
+
+def attention_groups(qkv, groups, valids, heads, d, p_drop=0.0):
+    """qkv [rows, 3 heads d] contiguous; groups [(first row, sequences, length)] tiling the rows; valids: per group [N, L] bool or None."""
+    assert qkv.dim() == 2 and qkv.is_contiguous() and sum(N * L for _, N, L in groups) == qkv.shape[0]
+    return AttentionGroupsFn.apply(qkv, heads, d, p_drop, tuple(groups), *[_u8(v) for v in valids])
+
+
+class SplitRowsFn(Function):
+    """Row ranges of a [rows, C] tensor as separate [N, L, C] views; backward gathers the range gradients into ONE buffer (autograd's
+    own slicing would build a zero-filled full-size tensor per range and add them)."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        ctx.groups, ctx.shape = groups, x.shape
+        return tuple(x[r0:r0 + N * L].view(N, L, x.shape[1]) for r0, N, L in groups)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rows, C = ctx.shape
+        like = next(g for g in grads if g is not None)
+        parts = [g.reshape(N * L, C) if g is not None else like.new_zeros(N * L, C) for (r0, N, L), g in zip(ctx.groups, grads)]
+        return torch.cat(parts, dim=0), None
+
+
+def split_rows(x, groups):
+    return SplitRowsFn.apply(x, tuple(groups))
+
+
 # ----------------------------------------------------------------------------------------------
 # batched matmul for the Interaction chain:  C[n] = A[n] op(B[n])  (+ row / column rank-1 terms)
 # ----------------------------------------------------------------------------------------------

@@ -115,3 +115,53 @@ def test_seq_encoder_eval_uses_the_chain_and_training_does_not(bf16_mode):
         _abi.call = raw
     assert n_eval == 4 and calls.get("case_encoder_chain", 0) == 4, calls.get("case_encoder_chain", 0)
     assert (y_eval.float() - y_train.float()).abs().max().item() <= 3e-2 * y_train.float().abs().max().item()
+
+
+def test_shared_encoder_runs_query_and_passages_in_one_pass(bf16_mode):
+    """TransformerSeqEncoder.forward_many (training, bf16): the query rows ride along with the passage rows through every row-local
+    launch; outputs equal the two separate passes (a GEMM row does not depend on its neighbours), parameter gradients agree up to the
+    summation order of the weight gradients, and the launch count of the row-local work is that of ONE pass."""
+    import case_rg_amd
+    from case_rg_amd import _abi
+    from case_rg_amd.utils import fill_params
+    ns = case_rg_amd.namespace()
+    enc = fill_params(ns.TransformerSeqEncoder(2, 8, 500, 512), 5, gain=2.0).to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    B, P, Lp, Lq = 4, 3, 128, 64
+    query = torch.randint(1, 500, (B, 1, Lq), generator=g)
+    passage = torch.randint(1, 500, (B, P, Lp), generator=g)
+    query[:, :, 50:] = 0
+    passage[1, 2, 2:] = 0
+    query, passage = query.to(DEV), passage.to(DEV)
+    wq = torch.randn(B, 1, 1, Lq, 512, generator=g).to(DEV)
+    wp = torch.randn(B, P, 1, Lp, 512, generator=g).to(DEV)
+    calls, raw = {}, _abi.call
+
+    def counting(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return raw(name, *a)
+
+    res = []
+    for merged in (True, False):
+        enc.zero_grad()
+        calls.clear()
+        _abi.call = counting
+        try:
+            if merged:
+                (oq, sq), (op, sp) = enc.forward_many([query, passage])
+            else:
+                (oq, sq), (op, sp) = enc(query), enc(passage)
+            loss = (oq.float() * wq).sum() + (op.float() * wp).sum() + sq.float().sum() + sp.float().sum()
+            loss.backward()
+        finally:
+            _abi.call = raw
+        res.append((oq.detach().float(), op.detach().float(), sq.detach().float(), sp.detach().float(),
+                    {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.grad is not None}, dict(calls)))
+    (oq1, op1, sq1, sp1, g1, c1), (oq0, op0, sq0, sp0, g0, c0) = res
+    assert torch.equal(oq1, oq0) and torch.equal(op1, op0) and torch.equal(sq1, sq0) and torch.equal(sp1, sp0)
+    assert set(g1) == set(g0)
+    for n in g0:
+        denom = g0[n].norm().clamp_min(1e-12)
+        assert ((g1[n] - g0[n]).norm() / denom).item() < 2e-3, n
+    assert c1["case_attention_fwd"] == c0["case_attention_fwd"] == 4 and c1["case_attention_bwd"] == 4   # two groups x two layers
+    assert c1["case_layernorm_fwd"] * 2 == c0["case_layernorm_fwd"] and c1["case_gemm"] < 0.62 * c0["case_gemm"]
