@@ -236,7 +236,6 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
         for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kh][j], af[kh][i], acc[i][j], 0, 0, 0);
   }
   SC_STAMP(8)
-  SC_STAMP(9)
   // ---- epilogue.  acc[i][j][e] = score of query m0 + 64 wr + 16 i + lr, key 96 wc + 16 j + 4 lg + e -------------------------------------
   const int64_t grow0 = ((int64_t)n * g.heads + head) * g.Lq + m0;  // global row index of the tile's first query
   const uint32_t tile_bytes = (uint32_t)rows * (uint32_t)g.Lk * 2u;

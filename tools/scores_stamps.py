@@ -30,7 +30,7 @@ buf = (ctypes.c_uint64 * (256 * 16))()
 assert A.lib.case_attention_scores_stamps(buf) == 0
 raw = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(256, 16)
 names = {0: "item start", 1: "K step 0 ready", 2: "K step 1 ready", 3: "K step 2 ready", 4: "K step 3 ready", 5: "K step 4 ready",
-         8: "K loop done", 9: "next item's DMA issued", 10: "statistics exchanged", 11: "epilogue done"}
+         8: "K loop done", 10: "statistics exchanged", 11: "epilogue done"}
 ids = [i for i in sorted(names) if np.median(raw[:, i]) > 0]
 tot = 0
 for a, b in zip(ids[:-1], ids[1:]):
