@@ -496,7 +496,12 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     elif os.environ.get("CASE_FORCE_GRADSYNC"):  # rehearsal of the multi-GPU path on one GPU: a one-rank RCCL group, buckets + hooks live
-        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=device)
+        # (under torch.distributed.run the agent's store must be used -- an explicit tcp:// address makes the worker a CLIENT of a
+        # store nobody serves and the rendezvous hangs)
+        if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=device)
     rank = dist.get_rank() if world > 1 else 0
     if a.mode == "encoder":
         if rank == 0:
