@@ -466,7 +466,7 @@ def spawn_ranks(a):
     output.  Runs before this process has touched the GPU (torch.cuda.device_count() does not initialise it), and this process
     never does -- a program that holds the GPU must not be replaced by, or fork, another one on this pool."""
     have = torch.cuda.device_count()
-    if have < a.gpus:
+    if have < a.gpus and not os.environ.get("CASE_BENCH_SHARE_GPU"):
         raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s)" % (a.gpus, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -491,10 +491,18 @@ def main():
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch one rank per GPU" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # CASE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box, never a measurement): every rank runs on device 0 and the collectives go
+    # through gloo -- RCCL refuses two ranks on one device; the launch, the rank bookkeeping and GradSync's bucket protocol are the real ones
+    share = bool(os.environ.get("CASE_BENCH_SHARE_GPU"))
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        if share:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     elif os.environ.get("CASE_FORCE_GRADSYNC"):  # rehearsal of the multi-GPU path on one GPU: a one-rank RCCL group, buckets + hooks live
         # (under torch.distributed.run the agent's store must be used -- an explicit tcp:// address makes the worker a CLIENT of a
         # store nobody serves and the rendezvous hangs)
