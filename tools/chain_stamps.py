@@ -22,9 +22,15 @@ enc = fill_params(ns.TransformerEncoder(layer, 2), 3, gain=2.0).to(dev).eval()
 N, L = 640, 384
 x = torch.randn(N, L, 512, device=dev).to(torch.bfloat16)
 s = torch.randn(N, L, 512, device=dev).to(torch.bfloat16)
+variant = sys.argv[1] if len(sys.argv) > 1 else "full"
 with torch.no_grad():
     for _ in range(3):
-        s_out, qkv = ops.encoder_chain("full", x, s, enc.layers[0], enc.layers[1])
+        if variant == "head":
+            s_out, qkv = ops.encoder_chain("head", x, None, None, enc.layers[0])
+        elif variant == "tail":
+            s_out, qkv = ops.encoder_chain("tail", x, s, enc.layers[1], None)
+        else:
+            s_out, qkv = ops.encoder_chain("full", x, s, enc.layers[0], enc.layers[1])
     torch.cuda.synchronize()
 import ctypes
 from case_rg_amd import _abi
