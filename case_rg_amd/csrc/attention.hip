@@ -38,6 +38,7 @@
 // Dropout uses the same counter RNG and the same element index ((n*h + head)*Lq + q)*Lk + k as the unfused softmax
 // kernel, so fused and unfused paths draw identical masks.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -866,11 +867,26 @@ extern "C" int case_attention_bwd_supported(int64_t head_dim) { return case_atte
                NAME ": operands must be 16-byte aligned with strides that are multiples of 8 elements");                                  \
   CASE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, NAME ": drop_p out of range")
 
+// K18 (attn64.hip): the whole (sequence, head) resident in one twelve-wave workgroup; head_dim 64, 288 < Lk <= 384, not causal.
+// CASE_ATTN_RESIDENT=0 keeps the flash-style kernels of this file for A/B measurements (read once).
+int case_attention_resident_ok(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const void* out);
+int case_attention_resident_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out,
+                                float* lse, hipStream_t s);
+static bool resident_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("CASE_ATTN_RESIDENT");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 extern "C" int case_attention_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                                   void* out, float* lse, case_stream_t stream) {
   CASE_REQUIRE(d && q && k && v && out && lse, "case_attention_fwd: null argument");
   CASE_ATTN_COMMON_CHECKS("case_attention_fwd");
   CASE_REQUIRE((uintptr_t)out % 8 == 0 && d->ldo % 4 == 0, "case_attention_fwd: out must be 8-byte aligned, ldo a multiple of 4");
+  if (resident_enabled() && (uintptr_t)key_valid % 4 == 0 && case_attention_resident_ok(d, q, k, v, out))
+    return case_attention_resident_fwd(d, q, k, v, key_valid, out, lse, (hipStream_t)stream);
   FaArgs a = {};
   fill_args(a, d, q, k, v, key_valid);
   a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse;

@@ -1,0 +1,557 @@
+// K18: head_dim-64 self-attention with the (sequence, head) RESIDENT in one workgroup (gfx950, bf16 in, f32 accumulate).
+//
+// nn.MultiheadAttention at head_dim 64 over the 384-token passages (common/TransformerEncoder.py:67, the H-wide blocks of
+// common/TransformerBlock.py:26) is the attention the training step and the encoder-forward point spend their time in.  The
+// flash-style kernels of attention.hip (four waves, one 64-key tile per barrier, register staging) ran it latency-bound at
+// 0.15-0.22 of the MFMA peak with the vector pipe 67 % busy.  A (sequence, head) is small -- Q, K, V are 48 KiB each -- so
+// here ONE workgroup of twelve waves owns a whole (sequence, head): every byte of Q, K and V enters the chip once, by LDS-DMA,
+// on a stream that runs ahead of the arithmetic across items, and the twelve waves are a STATIC three-stage pipeline:
+//
+//   wave w owns queries 32 w .. 32 w + 31 (lane = query, as in attention.hip) and walks the keys in chunks of 96;
+//   per chunk it runs   QK  : S^T = K Q^T (12 MFMAs, K rows from LDS) + key mask + chunk maximum
+//                       SM  : online-softmax decision, 48 exponentials per lane, row sums, dropout
+//                       PV  : pack P to bf16, O^T += V^T P^T (12 MFMAs, V^T by ds_read_b64_tr_b16)
+//   one phase per INTERVAL (= one s_barrier); wave group r = w / 4 (one wave on each SIMD) runs r intervals behind group 0,
+//   so in every interval each SIMD has one wave in each phase: the exponentials of one wave always sit beside the MFMAs of
+//   the other two instead of all waves multiplying together and then all exponentiating together.
+//
+// Data movement is static too: 144 KiB (K, V, the next item's Q) per item = 144 pieces of 1 KiB, twelve per wave and item, issued
+// by buffer_load_dwordx4 ... lds at fixed places of the wave's own phase sequence (K piece in QK, V piece in PV, Q pieces in the
+// first two SM phases of an item).  K and V live in rings of four 12 KiB chunk slots (a K chunk is read in three consecutive
+// intervals, once by each group; a V chunk likewise two intervals later), the next item's Q rows replace the current ones as
+// soon as every group has taken its fragments.  A piece is issued >= 6 intervals before its first reader; every wave ends an
+// interval with a COUNTED s_waitcnt -- an immediate, because the schedule repeats every item -- that leaves exactly the
+// vector-memory operations of the last five intervals in flight, so the barrier that opens interval t publishes everything
+// issued before t - 4.  (One wave issues about one instruction per 4.4 cycles whatever its kind: the first version of this
+// kernel computed the schedule at run time and spent 40 % of every phase in scalar bookkeeping.)
+//
+// LDS images are plain 128-byte rows, swizzled on the SOURCE side of the DMA (the destination of an LDS-DMA is lane-linear):
+//   K, Q (row reads, ds_read_b128):  16-byte chunk c of row r at slot c ^ ((r >> 1) & 7)  -- conflict-free fragments
+//   V (transposed reads):            chunk c of row r at slot c ^ (4 ((r >> 1) & 1))       -- the four key rows of a
+//                                    ds_read_b64_tr_b16 block land on four different 64-byte quarters of the 256-byte bank row
+//
+// Scope (fa64::fwd_ok): head_dim 64, not causal, 288 < Lk <= 384 (four chunks), Lq <= 384, 16-byte aligned operands whose
+// sequences fit 32-bit buffer offsets.  Everything else stays with attention.hip.  Same arithmetic points as there: scores
+// in f32, base-2 online softmax with lazy rescale (here at most three decisions per row), P rounded to bf16 once, the same
+// counter RNG and element index for dropout (common.h), LSE in natural log.
+#include "common.h"
+
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+namespace fa64 {
+
+constexpr int CK = 96, NCH = 4, LMAX = 384, SLOT = CK * 128, NKS = 4, NVS = 4, LAK = 3, LAV = 3, DEPTH = 5, NTHR = 768;
+constexpr int K_OFF = 0, V_OFF = NKS * SLOT, Q_OFF = V_OFF + NVS * SLOT, M_OFF = Q_OFF + LMAX * 128, LDS_BYTES = M_OFF + 2 * 512;  // 148 480
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.69314718055994531f, RESCALE_THR = 8.f * LOG2E;
+
+struct Args {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  int64_t ldq, ldk, ldv, sq, sk, sv;
+  bf16_t* o; int64_t ldo, so;
+  float* lse;
+  const uint8_t* key_valid;
+  int N, heads, Lq, Lk, nitems;
+  float scale, drop_p;
+  uint64_t seed, offset;
+};
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(size_t)p);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(((size_t)p) >> 32) & 0xffff);
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// one LDS-DMA piece: 64 lanes x 16 bytes -> lds_addr + 16 lane.  Every byte of Q, K and V is read once chip-wide: streaming policy.
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+// 64 lanes x 4 bytes -> lds_addr + 4 lane (the key-validity bytes of an item: an ordinary load would make hipcc wait vmcnt(0) at
+// its use and drain the DMA stream, and an inline-asm register load leaves its destination unprotected against compiler copies)
+__device__ __forceinline__ void dma4(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+// all but the N youngest vector-memory operations of this wave are complete
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Vector-memory operations a wave issues at step s = 3 c + phase of an item (QK, SM, PV of chunks 0 .. 3) and the counted wait that
+// closes the step: the operations of the last DEPTH steps stay in flight.  STEADY: an item with a successor (step 0: the previous
+// item's five stores and K chunk 3; step 1: Q rows 0-95 and the two validity pieces; step 4: Q rows 96-383; QK: a K piece, PV: a
+// V piece).  LAST: the final item of the workgroup (K and V chunk 3 only), behind a STEADY item.  Smaller actual counts (first
+// item: everything older came from the drained prologue) only make the wait a no-op.
+struct Sched {
+  int steady[12], last[12];
+};
+constexpr Sched make_sched() {
+  const int ps[12] = {6, 3, 1, 1, 3, 1, 1, 0, 1, 1, 0, 1}, pl[12] = {6, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Sched r = {};
+  for (int s = 0; s < 12; ++s) {
+    int ns = 0, nl = 0;
+    for (int k = 0; k < DEPTH; ++k) {
+      const int t = s - k;
+      ns += ps[(t + 12) % 12];
+      nl += t >= 0 ? pl[t] : ps[t + 12];
+    }
+    r.steady[s] = ns;
+    r.last[s] = nl;
+  }
+  return r;
+}
+constexpr Sched SCHED = make_sched();
+static_assert(SCHED.steady[4] == 14 && SCHED.steady[11] == 3 && SCHED.last[0] == 9 && SCHED.last[7] == 0, "schedule table");
+#pragma clang diagnostic pop
+
+// accumulator registers 8 s2 .. 8 s2 + 7 -> B-operand fragment of k-step s2 (k order: row 16 s2 + 8 (j >> 2) + 4 half + (j & 3))
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
+  u32x4 w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = f32x2_to_bf16x2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
+  return *reinterpret_cast<bf16x8*>(&w);
+}
+
+// value of the OTHER 32-lane half's lane (l ^ 32) combined with this lane's: both halves hold partial statistics of one query
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+#ifdef FA64_STAMPS
+// diagnostic build only (tools/fa64_stamps.py): s_memtime of workgroup 0 at the end of each phase's work, after the counted wait and
+// after the barrier, intervals FA64_T0 .. FA64_T0 + 35, every wave.  No stamp exists in the shipped library.
+#ifndef FA64_T0
+#define FA64_T0 26
+#endif
+__device__ uint64_t g_fa64_stamps[12 * 36 * 3];
+#define FA64_STAMP(k) { if (blockIdx.x == 0 && tau >= FA64_T0 && tau < FA64_T0 + 36) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+    if (l == 0) g_fa64_stamps[(wave * 36 + (tau - FA64_T0)) * 3 + (k)] = t_; } }
+#else
+#define FA64_STAMP(k)
+#endif
+
+template <bool DROP>
+__global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, r32 = l & 31, half = l >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // persistent: XCD x (blockIdx.x & 7) owns a contiguous range of (sequence, head) items and cuts it evenly over its workgroups; a
+  // workgroup walks ITS range in order (head fastest), so the per-item bookkeeping is an increment
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nwx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int per = a.nitems >> 3, rem = a.nitems & 7;
+  const int xfirst = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per, xcount = per + (xcd < rem ? 1 : 0);
+  const int wper = xcount / nwx, wrem = xcount - wper * nwx;
+  const int my_items = wper + (wslot < wrem ? 1 : 0);
+  if (my_items == 0) return;
+  const int pid0 = xfirst + (wslot < wrem ? wslot * (wper + 1) : wrem * (wper + 1) + (wslot - wrem) * wper);
+
+  // descriptor of one (sequence, head) slice
+  // (only the two address words of a descriptor are kept per slice: sixteen scalar registers less than whole descriptors)
+  auto slice = [&](const void* base, int64_t seq_stride, int n, int head) {
+    return ((uint64_t)base + (uint64_t)(((int64_t)n * seq_stride + head * 64) * 2)) & 0x0000ffffffffffffull;
+  };
+  auto desc = [&](uint64_t p, uint32_t bytes) {
+    i32x4 r;
+    r[0] = (int)(uint32_t)p;
+    r[1] = (int)(uint32_t)(p >> 32);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+  };
+  const uint32_t qbytes = (uint32_t)(((int64_t)(a.Lq - 1) * a.ldq + 64) * 2), kbytes = (uint32_t)(((int64_t)(a.Lk - 1) * a.ldk + 64) * 2),
+                 vbytes = (uint32_t)(((int64_t)(a.Lk - 1) * a.ldv + 64) * 2);
+  const bool masked = a.key_valid != nullptr;
+  const uint32_t mbytes = masked ? (uint32_t)a.Lk : 0u;  // bytes beyond Lk read as zeros; without a mask: an empty range, nobody reads the zeros
+  auto mask_slice = [&](int n) {
+    return (masked ? (uint64_t)a.key_valid + (uint64_t)((int64_t)n * a.Lk) : (uint64_t)a.q) & 0x0000ffffffffffffull;
+  };
+
+  // ---- DMA lane offsets: this wave's piece of a 96-row chunk = rows 8 wave .. 8 wave + 7, lane -> row (l >> 3), slot l & 7
+  const int wr = 8 * wave + (l >> 3);
+  const unsigned vK = (unsigned)(wr * a.ldk * 2 + (((l & 7) ^ ((wr >> 1) & 7)) << 4));
+  const unsigned vQ = (unsigned)(wr * a.ldq * 2 + (((l & 7) ^ ((wr >> 1) & 7)) << 4));
+  const unsigned vV = (unsigned)(wr * a.ldv * 2 + (((l & 7) ^ (4 * ((wr >> 1) & 1))) << 4));
+  const unsigned vM = (unsigned)(4 * l);
+  const unsigned kstep = (unsigned)(CK * a.ldk * 2), vstep = (unsigned)(CK * a.ldv * 2), qstep = (unsigned)(CK * a.ldq * 2);
+  const unsigned piece = (unsigned)wave * 1024u;
+
+  // ---- fragment lane offsets
+  // row reads (K tiles, Q): lane (r32, half) takes chunk 2 s + half of row r32 at slot (2 s + half) ^ ((r32 >> 1) & 7)
+  int roff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) roff[s] = r32 * 128 + (((2 * s + half) ^ ((r32 >> 1) & 7)) << 4);
+  // transposed reads (V): 16-lane group (l >> 4) = (dhalf, half); lane 4 q + p of it addresses key row 4 half + q, columns 4 p .. 4 p + 3
+  // of the 16-column block 32 dt + 16 dhalf: chunk 4 dt + 2 dhalf + (p >> 1), at slot chunk ^ 4 ((q >> 1) & 1)
+  const int tq = (l & 15) >> 2, tp = l & 3, dhalf = (l >> 4) & 1;
+  int toff[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+    toff[dt] = (4 * half + tq) * 128 + (((4 * dt + 2 * dhalf + (tp >> 1)) ^ (4 * ((tq >> 1) & 1))) << 4) + (tp & 1) * 8;
+
+  // the item this wave computes (its group runs `grp` intervals behind group 0) and its successor in the workgroup's range
+  int my_n = pid0 / a.heads, my_head = pid0 - my_n * a.heads;
+  uint64_t ck, cv, nk, nv, nq, nm;  // K / V slices of this item; K / V / Q / validity slices of the next
+  ck = slice(a.k, a.sk, my_n, my_head);
+  cv = slice(a.v, a.sv, my_n, my_head);
+  nk = ck; nv = cv; nq = ck; nm = ck;
+
+  // ---- prologue: K chunks 0 .. 2, V chunks 0 .. 2, all of Q, the validity bytes of the first item
+  {
+    const i32x4 rq = desc(slice(a.q, a.sq, my_n, my_head), qbytes), rm = desc(mask_slice(my_n), mbytes);
+#pragma unroll
+    for (int c = 0; c < LAK; ++c) dma16(desc(ck, kbytes), vK, c * kstep, lds0 + K_OFF + c * SLOT + piece);
+#pragma unroll
+    for (int c = 0; c < LAV; ++c) dma16(desc(cv, vbytes), vV, c * vstep, lds0 + V_OFF + c * SLOT + piece);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) dma16(rq, vQ, c * qstep, lds0 + Q_OFF + c * SLOT + piece);
+    dma4(rm, vM, lds0 + M_OFF);
+    dma4(rm, vM + 256u, lds0 + M_OFF + 256);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float scale2 = a.scale * LOG2E;
+  const float keep_scale = (DROP && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+  const uint32_t thr = rng_threshold(a.drop_p);
+#ifdef FA64_STAMPS
+  int tau = grp;
+#endif
+
+  // group r idles r intervals (one barrier each) before its first phase and 2 - r after its last: every wave meets 12 items + 2 barriers
+  for (int k = 0; k < grp; ++k) __builtin_amdgcn_s_barrier();
+
+  const int q0 = 32 * wave, qi = q0 + r32;
+  bf16x8 qf[4];
+  f32x16 o[2], st[3];
+  float m = -INFINITY, lsum = 0.f, mx = 0.f;
+  uint32_t row_key = 0;
+  bool has_next = false, all_valid = true;
+
+  auto store_item = [&]() {
+    // O = O^T keep_scale / l as 16-byte pieces: lane pairs (l, l + 32) hold columns 8 g + {0..3} / {4..7}; after the half swap the
+    // lower lane owns all 8 columns of an even g and the upper lane those of g + 1.  Always 5 store instructions (the counted waits
+    // rely on it): rows beyond Lq fall outside the descriptors.
+    // (the lane's row / column offsets are recomputed from an opaque lane id: hoisted out of the item loop they cost six registers
+    // that hipcc spilled to scratch -- and a scratch reload waits vmcnt(0), draining the DMA stream)
+    int lane_ = l;
+    asm volatile("" : "+v"(lane_));
+    const int half = lane_ >> 5, qi = 32 * wave + (lane_ & 31);
+    const float tot = half_sum(lsum);
+    const float inv = tot > 0.f ? keep_scale / tot : 0.f;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.o + (int64_t)my_n * a.so + my_head * 64), 0, (int)(((int64_t)(a.Lq - 1) * a.ldo + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.lse + ((int64_t)my_n * a.heads + my_head) * a.Lq), 0, (int)(a.Lq * 4), 0x00020000);
+    const int orow = qi * (int)a.ldo * 2;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        uint32_t x[2], y[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          x[i] = f32x2_to_bf16x2(o[dt][8 * gp + 2 * i] * inv, o[dt][8 * gp + 2 * i + 1] * inv);          // g = 2 gp
+          y[i] = f32x2_to_bf16x2(o[dt][8 * gp + 4 + 2 * i] * inv, o[dt][8 * gp + 4 + 2 * i + 1] * inv);  // g = 2 gp + 1
+          const auto sw = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);
+          x[i] = sw[0];
+          y[i] = sw[1];
+        }
+        const int vo = qi < a.Lq ? orow + (32 * dt + 16 * gp + 8 * half) * 2 : 0x7fffffff;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, ro, vo, 0, 0);
+      }
+    const float lse_v = tot > 0.f ? m * LN2 + __logf(tot) : -INFINITY;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lse_v), rl, (half == 0 && qi < a.Lq) ? qi * 4 : 0x7fffffff, 0, 0);
+  };
+
+  // closing step S of an item: counted wait, then the barrier that publishes what has landed
+  auto close = [&](auto step) {
+    constexpr int S = decltype(step)::value;
+    __builtin_amdgcn_sched_barrier(0);  // (with the empty asm at the end of each phase: the phase's arithmetic stays in its interval)
+    FA64_STAMP(0)
+    if (has_next) wait_vm<SCHED.steady[S]>();
+    else wait_vm<SCHED.last[S]>();
+    FA64_STAMP(1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FA64_STAMP(2)
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef FA64_STAMPS
+    ++tau;
+#endif
+  };
+
+  // one chunk of 96 keys: three phases, each one interval
+  auto chunk = [&](auto cc, int item) {
+    constexpr int c = decltype(cc)::value;
+    // ================================================ QK ================================================
+    if constexpr (c == 0) {
+      if (item > 0) {
+        store_item();
+        ++my_head;
+        if (my_head == a.heads) {
+          my_head = 0;
+          ++my_n;
+        }
+        ck = nk;
+        cv = nv;
+      }
+      has_next = item + 1 < my_items;
+      if (has_next) {
+        const int nh = my_head + 1 < a.heads ? my_head + 1 : 0, nn = my_head + 1 < a.heads ? my_n : my_n + 1;
+        nk = slice(a.k, a.sk, nn, nh);
+        nv = slice(a.v, a.sv, nn, nh);
+        nq = slice(a.q, a.sq, nn, nh);
+        nm = mask_slice(nn);
+      }
+      dma16(desc(ck, kbytes), vK, 3u * kstep, lds0 + K_OFF + 3 * SLOT + piece);  // K chunk 3 of this item
+    } else {
+      if (has_next) dma16(desc(nk, kbytes), vK, (unsigned)(c - 1) * kstep, lds0 + K_OFF + (c - 1) * SLOT + piece);  // K chunk c - 1 of the next
+    }
+    if constexpr (c == 0) {
+      const char* qb = smem + Q_OFF + q0 * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qb + roff[s]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+      m = -INFINITY;
+      lsum = 0.f;
+      if (DROP) row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)my_n * a.heads + my_head) * a.Lq + qi));
+      // every key of the item valid?  (bytes beyond Lk were written as zeros)
+      if (masked) {
+        int lane_ = l;
+        asm volatile("" : "+v"(lane_));  // (not hoisted out of the item loop: see store_item)
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(smem + M_OFF + (item & 1) * 512);
+        all_valid = __ballot(mw[lane_] == 0x01010101u && mw[64 + (lane_ & 31)] == 0x01010101u) == ~0ull;  // 96 dwords = 384 keys
+      } else {
+        all_valid = a.Lk == LMAX;
+      }
+    }
+    {
+      const char* kb = smem + K_OFF + c * SLOT;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 4096 + roff[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kb + t * 4096 + roff[s]), qf[s], st[t], 0, 0, 0);
+      }
+    }
+    if (!all_valid) {
+      // validity of this chunk's 96 keys as wave-uniform words
+      uint64_t km0;
+      uint32_t km1;
+      if (masked) {
+        const uint8_t* mbuf = reinterpret_cast<const uint8_t*>(smem + M_OFF + (item & 1) * 512 + CK * c);
+        km0 = __ballot(mbuf[l] != 0);
+        km1 = (uint32_t)__ballot(l < 32 && mbuf[64 + (l & 31)] != 0);
+      } else {
+        km0 = __ballot(CK * c + l < a.Lk);
+        km1 = (uint32_t)__ballot(l < 32 && CK * c + 64 + l < a.Lk);
+      }
+      const uint64_t m0 = km0 >> (4 * half);
+      const uint32_t m1 = km1 >> (4 * half);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int bit = (e & 3) + 8 * (e >> 2);
+          const bool ok = t < 2 ? ((m0 >> (bit + 32 * t)) & 1ull) != 0ull : ((m1 >> bit) & 1u) != 0u;
+          st[t][e] = ok ? st[t][e] : -INFINITY;
+        }
+    }
+    mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int e = (t == 0 ? 3 : 0); e + 1 < 16; e += 2) mx = fmaxf(fmaxf(mx, st[t][e]), st[t][e + 1]);
+    mx = fmaxf(fmaxf(mx, st[1][15]), st[2][15]);  // (tile 0 ends on an odd count: its register 15 was taken in the loop)
+    // hipcc moves register-only arithmetic across s_barrier (IR-level sinking towards the use): values that must exist when the
+    // interval closes pass through an empty asm
+    asm volatile("" : "+v"(mx), "+v"(st[0]), "+v"(st[1]), "+v"(st[2]));
+    close(std::integral_constant<int, 3 * c>{});
+
+    // ================================================ SM ================================================
+    if constexpr (c == 0) {
+      if (has_next) {  // the next item's Q rows 0 .. 95 (group 0 took its fragments an interval ago) and its validity bytes
+        dma16(desc(nq, qbytes), vQ, 0u, lds0 + Q_OFF + piece);
+        const unsigned mb = lds0 + M_OFF + ((item + 1) & 1) * 512;
+        const i32x4 rm = desc(nm, mbytes);
+        dma4(rm, vM, mb);
+        dma4(rm, vM + 256u, mb + 256);
+      }
+    } else if constexpr (c == 1) {
+      if (has_next) {  // rows 96 .. 383 (every group has its fragments)
+        const i32x4 rq = desc(nq, qbytes);
+        dma16(rq, vQ, qstep, lds0 + Q_OFF + SLOT + piece);
+        dma16(rq, vQ, 2u * qstep, lds0 + Q_OFF + 2 * SLOT + piece);
+        dma16(rq, vQ, 3u * qstep, lds0 + Q_OFF + 3 * SLOT + piece);
+      }
+    }
+    {
+      mx = half_max(mx) * scale2;  // scale2 > 0: the maximum commutes with the scaling
+      if constexpr (c == 0) {
+        m = mx;
+      } else {
+        if (__any(mx > m + RESCALE_THR)) {
+          // lazy rescale: the reference maximum moves only when some query's chunk maximum exceeds it by more than THR
+          const float m_new = fmaxf(m, mx);
+          const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
+          lsum *= alpha;
+          m = m_new;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        }
+      }
+      const float mref = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[t][e] = __builtin_amdgcn_exp2f(fmaf(st[t][e], scale2, -mref));
+      if constexpr (DROP) {
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ps += st[t][e];
+        lsum += ps;
+      }
+      if constexpr (DROP) {  // lane = one row of the probability matrix; registers = columns CK c + 32 t + 8 gg + 4 half + {0..3}
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const uint32_t base = (((uint32_t)(CK * c + 32 * t) >> 1) + 2u * (uint32_t)half) * RNG_C1;
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const uint32_t bits = rng_pair_bits_pre(row_key, base + (uint32_t)(4 * gg + i) * RNG_C1);
+              st[t][4 * gg + 2 * i] = (bits & 0xffffu) >= thr ? st[t][4 * gg + 2 * i] : 0.f;
+              st[t][4 * gg + 2 * i + 1] = (bits >> 16) >= thr ? st[t][4 * gg + 2 * i + 1] : 0.f;
+            }
+          __builtin_amdgcn_sched_barrier(0);  // one tile's hashes at a time (interleaving all 24 spills registers)
+        }
+      }
+    }
+    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(lsum));
+    close(std::integral_constant<int, 3 * c + 1>{});
+
+    // ================================================ PV ================================================
+    if constexpr (c == 0) {
+      dma16(desc(cv, vbytes), vV, 3u * vstep, lds0 + V_OFF + 3 * SLOT + piece);  // V chunk 3 of this item
+    } else {
+      if (has_next) dma16(desc(nv, vbytes), vV, (unsigned)(c - 1) * vstep, lds0 + V_OFF + (c - 1) * SLOT + piece);  // V chunk c - 1 of the next
+    }
+    {
+      // row sum of the probabilities
+      if constexpr (!DROP) {  // (with dropout the sum runs in SM, in front of the mask)
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ps += st[t][e];
+        lsum += ps;
+      }
+      const char* vb = smem + V_OFF + c * SLOT;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack_acc(st[t], s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const char* p = vb + t * 4096 + s2 * 2048 + toff[dt];
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 1024));
+            bf16x8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+    }
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(lsum));
+    close(std::integral_constant<int, 3 * c + 2>{});
+  };
+
+  for (int item = 0; item < my_items; ++item) {
+    chunk(std::integral_constant<int, 0>{}, item);
+    chunk(std::integral_constant<int, 1>{}, item);
+    chunk(std::integral_constant<int, 2>{}, item);
+    chunk(std::integral_constant<int, 3>{}, item);
+  }
+  store_item();
+  for (int k = 0; k < 2 - grp; ++k) __builtin_amdgcn_s_barrier();
+}
+
+bool fwd_ok(const CaseAttnDesc* d) {
+  if (d->head_dim != 64 || d->causal || d->Lk <= 288 || d->Lk > LMAX || d->Lk % 4 || d->Lq > LMAX || d->Lq < 1) return false;
+  const int64_t span_q = ((d->Lq - 1) * d->ldq + 64) * 2, span_k = ((d->Lk - 1) * d->ldk + 64) * 2, span_v = ((d->Lk - 1) * d->ldv + 64) * 2;
+  const int64_t span_o = ((d->Lq - 1) * d->ldo + 64) * 2;
+  return span_q < (1ll << 31) && span_k < (1ll << 31) && span_v < (1ll << 31) && span_o < (1ll << 31) && d->ldo % 8 == 0 && d->so % 8 == 0 &&
+         d->N * d->heads < (1ll << 30);
+}
+
+int launch_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
+               hipStream_t s) {
+  Args a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv;
+  a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse; a.key_valid = key_valid;
+  a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.nitems = (int)(d->N * d->heads);
+  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_attention_fwd: cannot raise the dynamic LDS limit");
+    int dev = 0, v2 = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v2, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v2 > 0) cus = v2;
+    cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+  }
+  const int grid = a.nitems < cus ? a.nitems : cus;
+  if (a.drop_p > 0.f) hipLaunchKernelGGL(fwd_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(fwd_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
+  return case_check_launch("case_attention_fwd (resident)");
+}
+
+}  // namespace fa64
+
+#ifdef FA64_STAMPS
+extern "C" int case_attention_resident_stamps(uint64_t* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fa64::g_fa64_stamps), sizeof(fa64::g_fa64_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// used by attention.hip's dispatch
+int case_attention_resident_ok(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const void* out) {
+  return fa64::fwd_ok(d) && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0;
+}
+int case_attention_resident_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out,
+                                float* lse, hipStream_t s) {
+  return fa64::launch_fwd(d, q, k, v, key_valid, out, lse, s);
+}

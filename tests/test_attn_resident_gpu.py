@@ -1,0 +1,85 @@
+"""K18 (csrc/attn64.hip): head_dim-64 attention with the (sequence, head) resident in one twelve-wave workgroup -- the forward
+and (later) the single-pass backward against an f32 restatement of F.multi_head_attention_forward's bmm -> softmax -> bmm chain on
+the same bf16 inputs (common/TransformerEncoder.py:67, common/TransformerBlock.py:26), and against the flash-style kernels of
+attention.hip it replaces (identical dropout masks)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from case_rg_amd import ops
+    return ops
+
+
+def _reference(qkv, valid, h, d):
+    N, L, _ = qkv.shape
+    E = h * d
+    q, k, v = qkv.float().split(E, dim=-1)
+    qh, kh, vh = [t.reshape(N, L, h, d).transpose(1, 2) for t in (q, k, v)]
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    return (p @ vh).transpose(1, 2).reshape(N, L, E), torch.logsumexp(s, -1)
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("N,h,L", [(2, 8, 384), (3, 8, 320), (1, 2, 292), (40, 8, 384), (33, 3, 352)])
+def test_resident_forward_matches_reference(N, h, L):
+    """Full and ragged validity (one sequence cut in the second chunk, one with a single valid key, one with none), fewer and more
+    items than workgroups (40 x 8 = 320 items on 256 persistent workgroups: the DMA stream crosses item boundaries)."""
+    from case_rg_amd import _abi
+    ops = _ops()
+    d, E = 64, h * 64
+    ad = _abi.AttnDesc()
+    g = torch.Generator().manual_seed(L + N)
+    qkv = (torch.randn(N, L, 3 * E, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    valid = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    valid[N - 1, L // 2 + 3:] = False
+    if N > 2:
+        valid[1, 1:] = False
+        valid[2, :] = False
+        valid[N - 2] = (torch.rand(L, generator=g) > 0.3).to(DEV)
+    o = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=valid)
+    ref, _ = _reference(qkv, valid, h, d)
+    err = _rel(o, ref)
+    assert err < 6e-3, err
+    if N > 2:
+        assert torch.count_nonzero(o[2]) == 0, "no valid key: exact zeros"
+    assert torch.isfinite(o.float()).all()
+
+
+def test_resident_forward_equals_flash_kernels_with_dropout():
+    """Same counter RNG and element index as the flash-style kernel and the unfused softmax: the dropped-out outputs agree to bf16
+    rounding of P (the masks are identical); LSE agrees to f32 rounding."""
+    from case_rg_amd import _abi, config
+    ops = _ops()
+    N, h, L, d = 5, 8, 384, 64
+    E = h * d
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(N, L, 3 * E, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    valid = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    valid[3, 200:] = False
+    config.set_dropout(True)
+    try:
+        outs = []
+        for unfused in (False, True):
+            config.manual_seed(11)
+            saved = _abi.lib.case_attention_supported
+            try:
+                if unfused:
+                    _abi.lib.case_attention_supported = lambda _d: 0
+                outs.append(ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=valid, p_drop=0.1))
+            finally:
+                _abi.lib.case_attention_supported = saved
+        err = _rel(outs[0], outs[1])
+        assert err < 8e-3, err
+    finally:
+        config.set_dropout(False)
