@@ -49,6 +49,12 @@ namespace fa64 {
 
 constexpr int CK = 96, NCH = 4, LMAX = 384, SLOT = CK * 128, NKS = 4, NVS = 4, LAK = 3, LAV = 3, DEPTH = 5, NTHR = 768;
 constexpr int K_OFF = 0, V_OFF = NKS * SLOT, Q_OFF = V_OFF + NVS * SLOT, M_OFF = Q_OFF + LMAX * 128, LDS_BYTES = M_OFF + 2 * 512;  // 148 480
+// s_setprio per phase: measured flat (0 / 2 / 1, 1 / 3 / 2, 0 / 1 / 2, 2 / 1 / 0 against none: 0.157-0.162 ms all) -- not emitted
+#ifndef FA64_PRIO_QK
+#define FA64_PRIO_QK 0
+#define FA64_PRIO_SM 0
+#define FA64_PRIO_PV 0
+#endif
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.69314718055994531f, RESCALE_THR = 8.f * LOG2E;
 
 struct Args {
@@ -213,6 +219,10 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
   ck = slice(a.k, a.sk, my_n, my_head);
   cv = slice(a.v, a.sv, my_n, my_head);
   nk = ck; nv = cv; nq = ck; nm = ck;
+  // byte step from the last head of a sequence to head 0 of the next (48-bit addresses: no carry into the descriptor's upper bits for
+  // tensors below 2^47)
+  const int64_t seqstep_k = (a.sk - (int64_t)(a.heads - 1) * 64) * 2, seqstep_v = (a.sv - (int64_t)(a.heads - 1) * 64) * 2,
+                seqstep_q = (a.sq - (int64_t)(a.heads - 1) * 64) * 2;
 
   // ---- prologue: K chunks 0 .. 2, V chunks 0 .. 2, all of Q, the validity bytes of the first item
   {
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
   auto chunk = [&](auto cc, int item) {
     constexpr int c = decltype(cc)::value;
     // ================================================ QK ================================================
+    if constexpr (FA64_PRIO_QK != 0 || FA64_PRIO_SM != 0 || FA64_PRIO_PV != 0) __builtin_amdgcn_s_setprio(FA64_PRIO_QK);
     if constexpr (c == 0) {
       if (item > 0) {
         store_item();
@@ -315,12 +326,12 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
         cv = nv;
       }
       has_next = item + 1 < my_items;
-      if (has_next) {
-        const int nh = my_head + 1 < a.heads ? my_head + 1 : 0, nn = my_head + 1 < a.heads ? my_n : my_n + 1;
-        nk = slice(a.k, a.sk, nn, nh);
-        nv = slice(a.v, a.sv, nn, nh);
-        nq = slice(a.q, a.sq, nn, nh);
-        nm = mask_slice(nn);
+      if (has_next) {  // the successor's slices: the next head of this sequence, or head 0 of the next sequence
+        const bool wrap = my_head + 1 == a.heads;
+        nk = ck + (uint64_t)(wrap ? seqstep_k : 128);
+        nv = cv + (uint64_t)(wrap ? seqstep_v : 128);
+        nq = (item == 0 ? slice(a.q, a.sq, my_n, my_head) : nq) + (uint64_t)(wrap ? seqstep_q : 128);
+        nm = (item == 0 ? mask_slice(my_n) : nm) + (uint64_t)(wrap && masked ? a.Lk : 0);
       }
       dma16(desc(ck, kbytes), vK, 3u * kstep, lds0 + K_OFF + 3 * SLOT + piece);  // K chunk 3 of this item
     } else {
@@ -330,10 +341,6 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
       const char* qb = smem + Q_OFF + q0 * 128;
 #pragma unroll
       for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qb + roff[s]);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
       m = -INFINITY;
       lsum = 0.f;
       if (DROP) row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)my_n * a.heads + my_head) * a.Lq + qi));
@@ -393,6 +400,7 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
     close(std::integral_constant<int, 3 * c>{});
 
     // ================================================ SM ================================================
+    if constexpr (FA64_PRIO_QK != 0 || FA64_PRIO_SM != 0 || FA64_PRIO_PV != 0) __builtin_amdgcn_s_setprio(FA64_PRIO_SM);
     if constexpr (c == 0) {
       if (has_next) {  // the next item's Q rows 0 .. 95 (group 0 took its fragments an interval ago) and its validity bytes
         dma16(desc(nq, qbytes), vQ, 0u, lds0 + Q_OFF + piece);
@@ -459,6 +467,7 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
     close(std::integral_constant<int, 3 * c + 1>{});
 
     // ================================================ PV ================================================
+    if constexpr (FA64_PRIO_QK != 0 || FA64_PRIO_SM != 0 || FA64_PRIO_PV != 0) __builtin_amdgcn_s_setprio(FA64_PRIO_PV);
     if constexpr (c == 0) {
       dma16(desc(cv, vbytes), vV, 3u * vstep, lds0 + V_OFF + 3 * SLOT + piece);  // V chunk 3 of this item
     } else {
@@ -489,7 +498,12 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
             bf16x8 vf;
             vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
             vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            if (c == 0 && t == 0 && s2 == 0) {  // an item's first product starts the accumulators (no zero fill)
+              const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, zero, 0, 0, 0);
+            } else {
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
           }
         }
     }
