@@ -117,6 +117,8 @@ def _load():
     lib.case_optim_chunk_elems.argtypes = []
     lib.case_encoder_chain_packed_bytes.restype = C.c_int64
     lib.case_encoder_chain_packed_bytes.argtypes = []
+    lib.case_attention_bwd_scratch_floats.restype = C.c_int64
+    lib.case_attention_bwd_scratch_floats.argtypes = [C.POINTER(AttnDesc)]
     lib.case_version.restype = C.c_int
     lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()
     lib.case_gemm_tile_for.argtypes = [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr]

@@ -872,12 +872,30 @@ extern "C" int case_attention_bwd_supported(int64_t head_dim) { return case_atte
 int case_attention_resident_ok(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const void* out);
 int case_attention_resident_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out,
                                 float* lse, hipStream_t s);
+// K19: the single-pass backward of the same shapes (needs 2 N heads Lq floats of scratch: case_attention_bwd_scratch_floats)
+int case_attention_resident_bwd_ok(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                   const void* dq, const void* dk, const void* dv);
+int case_attention_resident_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, const void* out,
+                                const float* lse, const void* dout, float* scratch, void* dq, void* dk, void* dv, hipStream_t s);
 static bool resident_enabled() {
   static const bool on = [] {
     const char* e = getenv("CASE_ATTN_RESIDENT");
     return !(e && e[0] == '0');
   }();
   return on;
+}
+
+static bool resident_bwd_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("CASE_ATTN_RESIDENT_BWD");
+    return resident_enabled() && !(e && e[0] == '0');
+  }();
+  return on;
+}
+// floats of scratch case_attention_bwd needs behind `delta`: N heads Lq for the flash-style kernels, twice that for K19
+extern "C" int64_t case_attention_bwd_scratch_floats(const CaseAttnDesc* d) {
+  if (!d) return 0;
+  return d->N * d->heads * d->Lq * 2;
 }
 
 extern "C" int case_attention_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
@@ -961,6 +979,8 @@ extern "C" int case_attention_bwd(const CaseAttnDesc* d, const void* q, const vo
                    (uintptr_t)dv % 8 == 0,
                "case_attention_bwd: operands must be 16-byte aligned with strides that are multiples of 8 elements");
   CASE_REQUIRE(d->ldo == d->heads * d->head_dim && d->so == d->Lq * d->ldo, "case_attention_bwd: out / dout must be contiguous [N, Lq, heads*head_dim]");
+  if (resident_bwd_enabled() && (uintptr_t)key_valid % 4 == 0 && case_attention_resident_bwd_ok(d, q, k, v, out, dout, dq, dk, dv))
+    return case_attention_resident_bwd(d, q, k, v, key_valid, out, lse, dout, delta, dq, dk, dv, (hipStream_t)stream);
   FaArgs a = {};
   fill_args(a, d, q, k, v, key_valid);
   a.lse = const_cast<float*>(lse);

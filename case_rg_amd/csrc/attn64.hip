@@ -553,7 +553,443 @@ int launch_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* 
   return case_check_launch("case_attention_fwd (resident)");
 }
 
+
+// =====================================================================================================================================
+// K19: single-pass backward of the same attention.  One workgroup = twelve waves = one (sequence, head); wave w keeps keys 32 w ..
+// 32 w + 31 STATIONARY (lane = key: K and V fragments and the dK^T / dV^T accumulators in registers, as attention.hip's dK / dV kernel)
+// while the workgroup sweeps the queries in tiles of 32.  Per tile and wave:
+//   step 1: S = Q K^T and dP = dO V^T (8 MFMAs; the accumulators START at -lse / scale and -delta, so p = 2^(scale2 S') and
+//           dS = p dP' need no subtraction and no per-row constants in registers), the exponentials, dS; the bf16 dS^T tile goes to LDS
+//   step 2: dV^T += dO^T P, dK^T += Q^T dS (8 MFMAs, the A operands by transposed reads of the SAME Q / dO tile images), and the
+//           tile's dQ = dS K: eight pieces of 16 queries x 16 head-dim columns (waves 0 .. 7, one each), each a full contraction
+//           over the 384 keys (12 x v_mfma_f32_16x16x32_bf16) from the dS^T tile and the K image -- no partial sums, no atomics,
+//           ONE exponential per score and no second pass over Q / K / V / dO (the flash-style pair of kernels recomputes S, the
+//           exponential and the dropout hash for dQ).
+// Two barriers per tile (dS^T is the only thing that crosses waves).  Q / dO tiles, their -lse / scale and -delta rows and the NEXT
+// item's K image arrive by LDS-DMA three tiles ahead (waves 0 .. 7: one Q or dO piece per tile; waves 8 .. 11: the K image and the
+// statistics); the K image is double buffered, so the sweep runs on across items; the next item's V fragments are requested into
+// dead registers during the last tile.  Images: 128-byte rows, 16-byte chunk c of row r at slot c ^ f((r >> 1) & 7),
+// f(y) = (y0 << 2) | (y2 << 1) | y1: conflict-free for the ds_read_b128 row fragments, the 32 x 32 transposed fragments AND the
+// 16 x 16 transposed fragments of the dQ product.  dS^T rows are 64 bytes (32 queries): 8-byte unit u of key row k at u ^ 4 ((k >> 3) & 1).
+// =====================================================================================================================================
+namespace bwd {
+
+constexpr int TQ = 32, NT = 768, KIMG = LMAX * 128, DS_OFF = 2 * KIMG, DS_BYTES = LMAX * 64, RING_OFF = DS_OFF + DS_BYTES;
+constexpr int SL_Q = 0, SL_DO = 4096, SL_NL = 8192, SL_ND = 8448, SL_RK = 8704, SLOT_B = 8832, NSLOT = 4, LOOK = 3;
+constexpr int LDS_B = RING_OFF + NSLOT * SLOT_B;  // 158 208
+
+struct BArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout;
+  int64_t ldq, ldk, ldv, lddo, sq, sk, sv, sdo;
+  const float* negl; const float* negd;  // [N, heads, Lq]: -lse / scale, -delta
+  const uint8_t* key_valid;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  int N, heads, Lq, Lk, nitems, ntiles;
+  float scale, drop_p;
+  uint64_t seed, offset;
+};
+
+__device__ __forceinline__ int swz(int row) {  // f((row >> 1) & 7)
+  const int y = (row >> 1) & 7;
+  return ((y & 1) << 2) | ((y >> 2) << 1) | ((y >> 1) & 1);
+}
+
+// -lse / scale and -delta = -rowsum(dO * O) per (sequence, head, query): the accumulator initial values of S and dP
+__global__ __launch_bounds__(256) void stat_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const float* __restrict__ lse,
+                                                   float* __restrict__ negl, float* __restrict__ negd, int64_t rows, int heads, int Lq,
+                                                   float inv_scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (n Lq + q) heads + head
+  if (i >= rows * heads) return;
+  const int64_t row = i / heads;
+  const int head = (int)(i - row * heads);
+  const bf16_t* a = dout + row * heads * 64 + head * 64;
+  const bf16_t* b = out + row * heads * 64 + head * 64;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; c += 8) {
+    const uint4 x = *reinterpret_cast<const uint4*>(a + c), y = *reinterpret_cast<const uint4*>(b + c);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      acc += __uint_as_float(xs[k] << 16) * __uint_as_float(ys[k] << 16) + __uint_as_float(xs[k] & 0xffff0000u) * __uint_as_float(ys[k] & 0xffff0000u);
+  }
+  const int64_t n = row / Lq, q = row - n * Lq;
+  const int64_t o = (n * heads + head) * Lq + q;
+  negd[o] = -acc;
+  negl[o] = -lse[o] * inv_scale;  // lse = -inf (no valid key): +inf -> handled as p = 0 through the key mask of such a sequence
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmk() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm_small(int n) {  // all but the n youngest vector-memory operations are complete (n uniform, <= 15)
+  if (n < 4) {
+    if (n < 2) { if (n == 0) wait_vmk<0>(); else wait_vmk<1>(); } else { if (n == 2) wait_vmk<2>(); else wait_vmk<3>(); }
+  } else if (n < 8) {
+    if (n < 6) { if (n == 4) wait_vmk<4>(); else wait_vmk<5>(); } else { if (n == 6) wait_vmk<6>(); else wait_vmk<7>(); }
+  } else if (n < 12) {
+    if (n < 10) { if (n == 8) wait_vmk<8>(); else wait_vmk<9>(); } else { if (n == 10) wait_vmk<10>(); else wait_vmk<11>(); }
+  } else {
+    if (n < 14) { if (n == 12) wait_vmk<12>(); else wait_vmk<13>(); } else { if (n == 14) wait_vmk<14>(); else wait_vmk<15>(); }
+  }
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 tr_pair(const char* p, int hi_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + hi_off));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = l & 31, half = l >> 5;  // (the tile loop recomputes them from an opaque lane id)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // persistent: the item ranges of K18's forward
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nwx = ((int)gridDim.x - xcd + 7) >> 3;
+  const int per = a.nitems >> 3, rem = a.nitems & 7;
+  const int xfirst = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per, xcount = per + (xcd < rem ? 1 : 0);
+  const int wper = xcount / nwx, wrem = xcount - wper * nwx;
+  const int my_items = wper + (wslot < wrem ? 1 : 0);
+  if (my_items == 0) return;
+  const int pid0 = xfirst + (wslot < wrem ? wslot * (wper + 1) : wrem * (wper + 1) + (wslot - wrem) * wper);
+  const int ntiles = a.ntiles, total_tiles = my_items * ntiles;
+
+  auto slice = [&](const void* base, int64_t seq_stride, int n, int head) {
+    return ((uint64_t)base + (uint64_t)(((int64_t)n * seq_stride + head * 64) * 2)) & 0x0000ffffffffffffull;
+  };
+  auto desc = [&](uint64_t p, uint32_t bytes) {
+    i32x4 r;
+    r[0] = (int)(uint32_t)p;
+    r[1] = (int)(uint32_t)(p >> 32);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+  };
+  const uint32_t qbytes = (uint32_t)(((int64_t)(a.Lq - 1) * a.ldq + 64) * 2), kbytes = (uint32_t)(((int64_t)(a.Lk - 1) * a.ldk + 64) * 2),
+                 obytes = (uint32_t)(((int64_t)(a.Lq - 1) * a.lddo + 64) * 2), sbytes = (uint32_t)(a.Lq * 4);
+
+  // ---- this wave's DMA role: waves 0-3 a Q piece per tile, 4-7 a dO piece, 8-11 the next item's K image (+ 8: the statistics rows)
+  const int prow = 8 * (wave & 3) + (l >> 3);  // row of the 32-row tile (waves 0 .. 7); K image: row 8 piece + (l >> 3)
+  const unsigned vT = (unsigned)(prow * (wave < 4 ? a.ldq : a.lddo) * 2 + (((l & 7) ^ swz(prow)) << 4));
+  const unsigned tstep = (unsigned)(TQ * (wave < 4 ? a.ldq : a.lddo) * 2);
+  // K image piece p = rows 8 p .. 8 p + 7; the pieces a wave issues all have the parity of the wave (wave + 12 i in the prologue, wave - 8 + 4 j
+  // in the sweep), and the swizzle of row 8 p + r depends on p through its parity only
+  const int krow = l >> 3;
+  const unsigned vKi = (unsigned)(krow * a.ldk * 2 + (((l & 7) ^ swz(8 * (wave & 1) + krow)) << 4));
+  // ---- stream state: (sequence, head) of the item being computed and of the item the DMA stream (3 tiles ahead) is in
+  int my_n = pid0 / a.heads, my_head = pid0 - my_n * a.heads;
+  int dn = my_n, dh = my_head, dtile = 0, ditem = 0;  // DMA stream position
+  int n_cur = 0, n_prev = 0;
+  auto advance_item = [&](int& n, int& h) {
+    if (++h == a.heads) {
+      h = 0;
+      ++n;
+    }
+  };
+  // the pieces of stream tile (ditem, dtile) into ring slot `sl`
+  auto issue_tile = [&](int sl) {
+    const unsigned sb = lds0 + RING_OFF + sl * SLOT_B;
+    if (wave < 4) {
+      dma16(desc(slice(a.q, a.sq, dn, dh), qbytes), vT, (unsigned)dtile * tstep, sb + SL_Q + (wave & 3) * 1024);
+      ++n_cur;
+    } else if (wave < 8) {
+      dma16(desc(slice(a.dout, a.sdo, dn, dh), obytes), vT, (unsigned)dtile * tstep, sb + SL_DO + (wave & 3) * 1024);
+      ++n_cur;
+    } else if (wave == 8) {
+      const uint64_t off = (uint64_t)(((int64_t)dn * a.heads + dh) * a.Lq) * 4ull;
+      dma4(desc(((uint64_t)a.negl + off) & 0x0000ffffffffffffull, sbytes), (unsigned)(dtile * 128 + 4 * l), sb + SL_NL);
+      dma4(desc(((uint64_t)a.negd + off) & 0x0000ffffffffffffull, sbytes), (unsigned)(dtile * 128 + 4 * l), sb + SL_ND);
+      n_cur += 2;
+    }
+    if (DROP && wave == 9 && l < 32) {  // the dropout row keys of the tile's queries
+      const uint32_t rk = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)dn * a.heads + dh) * a.Lq + dtile * TQ + l));
+      *reinterpret_cast<uint32_t*>(smem + RING_OFF + sl * SLOT_B + SL_RK + 4 * l) = rk;
+    }
+  };
+  auto advance_stream = [&]() {
+    if (++dtile == ntiles) {
+      dtile = 0;
+      ++ditem;
+      advance_item(dn, dh);
+    }
+  };
+  // K image pieces of item (n, h) into buffer `buf`: pieces kw, kw + 4, .. (kw = wave - 8), two per call
+  auto issue_kimg = [&](int n, int h, int buf, int first_piece) {
+    const i32x4 rk = desc(slice(a.k, a.sk, n, h), kbytes);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = first_piece + 4 * i;
+      dma16(rk, vKi, (unsigned)(pc * 8 * a.ldk * 2), lds0 + buf * KIMG + pc * 1024);
+    }
+    n_cur += 2;
+  };
+
+  // ---- prologue: the first item's K image (4 pieces per wave), tiles 0 .. 2
+  {
+    const i32x4 rk = desc(slice(a.k, a.sk, my_n, my_head), kbytes);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = wave + 12 * i;
+      dma16(rk, vKi, (unsigned)(pc * 8 * a.ldk * 2), lds0 + pc * 1024);
+    }
+    for (int i = 0; i < LOOK; ++i) {
+      if (ditem < my_items) issue_tile(i);
+      advance_stream();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  n_cur = 0;
+
+  const float scale2 = a.scale * LOG2E;
+  const float keep_scale = (DROP && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+  const uint32_t thr = rng_threshold(a.drop_p);
+  const int k0 = 32 * wave, ki = k0 + r32;
+
+  bf16x8 kf[4], vf[4];
+  f32x16 dk[2], dv[2];
+  bool key_ok = true, keys_all_ok = true;
+  const uint32_t jc1 = ((uint32_t)ki >> 1) * RNG_C1, field_shift = 16u * ((uint32_t)ki & 1u);
+
+  auto load_item = [&](int buf) {  // stationary fragments of item (my_n, my_head): K rows from its image, V rows from memory
+    const char* kb = smem + buf * KIMG + k0 * 128 + r32 * 128;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kb + (((2 * s + half) ^ swz(r32)) << 4));
+    const int row = ki < a.Lk ? ki : a.Lk - 1;  // clamped: such a key is masked
+    const bf16_t* vp = a.v + (int64_t)my_n * a.sv + my_head * 64 + (int64_t)row * a.ldv + 8 * half;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
+    key_ok = ki < a.Lk && (!a.key_valid || a.key_valid[(int64_t)my_n * a.Lk + row] != 0);
+    keys_all_ok = __all(key_ok);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dk[dt][e] = dv[dt][e] = 0.f;
+  };
+  auto store_item = [&]() {  // dK = scale dK^T^T, dV = dV^T^T as 16-byte pieces (K18's store_item); rows beyond Lk fall outside the descriptors
+    int lane_ = l;
+    asm volatile("" : "+v"(lane_));
+    const int hf = lane_ >> 5, key = 32 * wave + (lane_ & 31);
+    const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dk + (int64_t)my_n * a.sk + my_head * 64), 0, (int)kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.dv + (int64_t)my_n * a.sv + my_head * 64), 0, (int)(((int64_t)(a.Lk - 1) * a.ldv + 64) * 2), 0x00020000);
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const f32x16& acc = which ? dv[dt] : dk[dt];
+          const float mul = which ? 1.f : a.scale;
+          uint32_t x[2], y[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            x[i] = f32x2_to_bf16x2(acc[8 * gp + 2 * i] * mul, acc[8 * gp + 2 * i + 1] * mul);
+            y[i] = f32x2_to_bf16x2(acc[8 * gp + 4 + 2 * i] * mul, acc[8 * gp + 4 + 2 * i + 1] * mul);
+            const auto sw = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);
+            x[i] = sw[0];
+            y[i] = sw[1];
+          }
+          const int ld = which ? (int)a.ldv : (int)a.ldk;
+          const int vo = key < a.Lk ? key * ld * 2 + (32 * dt + 16 * gp + 8 * hf) * 2 : 0x7fffffff;
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{x[0], x[1], y[0], y[1]}, which ? rdv : rdk, vo, 0, 0);
+        }
+    n_cur += 8;
+  };
+
+  load_item(0);
+  int T = 0;
+  for (int item = 0; item < my_items; ++item) {
+    const int kbuf = item & 1;
+    const bool has_next = item + 1 < my_items;
+    int nn = my_n, nh = my_head;
+    advance_item(nn, nh);
+    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dq + (int64_t)my_n * a.sq + my_head * 64), 0, (int)qbytes, 0x00020000);
+    for (int t = 0; t < ntiles; ++t, ++T) {
+      const char* slot = smem + RING_OFF + (T & 3) * SLOT_B;
+      // fragment lane offsets, recomputed per tile from an opaque lane id: hoisted out of the loops they (and the 48 addresses of the dQ
+      // product) cost more registers than the kernel has -- hipcc spilled 100 of them
+      int ln = l;
+      asm volatile("" : "+v"(ln));
+      const int r32 = ln & 31, half = ln >> 5;
+      // row reads (Q / dO tiles): chunk 2 s + half of row r32 at slot (2 s + half) ^ f(r32): s = 0 .. 3 differ by XOR 2 s
+      const int rbase = r32 * 128, rsw = swz(r32) ^ half;
+      // 32 x 32 transposed reads (Q^T, dO^T): 16-lane group (dhalf, half); lane 4 q + p: tile row 4 half + q (+ 8), chunk 4 dt + 2 dhalf + (p >> 1)
+      const int tq = (ln & 15) >> 2, tp = ln & 3, dhalf = (ln >> 4) & 1, trow = 4 * half + tq;
+      const int tlo = trow * 128 + (tp & 1) * 8, tcl = (2 * dhalf + (tp >> 1)) ^ swz(trow), tch = (2 * dhalf + (tp >> 1)) ^ swz(trow + 8);
+      // ======================================== step 1: S, dP, the exponentials, dS ========================================
+      if (T + LOOK < total_tiles) issue_tile((T + LOOK) & 3);
+      advance_stream();
+      if (has_next && wave >= 8 && t < 6) issue_kimg(nn, nh, kbuf ^ 1, (wave - 8) + 8 * t);
+      f32x16 st, dp;
+      {
+        const float* nl = reinterpret_cast<const float*>(slot + SL_NL) + 4 * half;
+        const float* nd = reinterpret_cast<const float*>(slot + SL_ND) + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(nl + 8 * g);
+          st[4 * g] = x[0]; st[4 * g + 1] = x[1]; st[4 * g + 2] = x[2]; st[4 * g + 3] = x[3];
+          if (!DROP) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(nd + 8 * g);
+            dp[4 * g] = y[0]; dp[4 * g + 1] = y[1]; dp[4 * g + 2] = y[2]; dp[4 * g + 3] = y[3];
+          } else {
+            dp[4 * g] = dp[4 * g + 1] = dp[4 * g + 2] = dp[4 * g + 3] = 0.f;
+          }
+        }
+        if (TQ * t + TQ > a.Lq) {  // rows beyond Lq (their statistics read as zeros): p = 0
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (TQ * t + (e & 3) + 8 * (e >> 2) + 4 * half >= a.Lq) st[e] = -INFINITY;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int ro = rbase + (((2 * s) ^ rsw) << 4);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + SL_Q + ro), kf[s], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + SL_DO + ro), vf[s], dp, 0, 0, 0);
+        }
+      }
+      // p = 2^(scale2 S'); the dropped-out probabilities (for dV) and dS / scale (the factor goes on the finished dK and dQ)
+      if constexpr (!DROP) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          st[e] = __builtin_amdgcn_exp2f(st[e] * scale2);
+          if (!keys_all_ok) st[e] = key_ok ? st[e] : 0.f;
+          dp[e] *= st[e];
+        }
+      } else {
+        const float* nd = reinterpret_cast<const float*>(slot + SL_ND) + 4 * half;
+        const uint32_t* rkp = reinterpret_cast<const uint32_t*>(slot + SL_RK) + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(nd + 8 * g);
+          const u32x4 rk4 = *reinterpret_cast<const u32x4*>(rkp + 8 * g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = 4 * g + i;
+            float pr = __builtin_amdgcn_exp2f(st[e] * scale2);
+            if (!keys_all_ok) pr = key_ok ? pr : 0.f;
+            const float kp = ((rng_pair_bits_pre(rk4[i], jc1) >> field_shift) & 0xffffu) >= thr ? keep_scale : 0.f;
+            dp[e] = pr * fmaf(dp[e], kp, d4[i]);  // P (keep / (1 - p) dP - delta)
+            st[e] = pr * kp;
+          }
+        }
+      }
+      const bf16x8 pf0 = pack_acc(st, 0), pf1 = pack_acc(st, 1), df0 = pack_acc(dp, 0), df1 = pack_acc(dp, 1);
+      {
+        // dS^T[key][query]: this lane's key row, four queries (8 bytes) per unit 2 g + half
+        char* dsr = smem + DS_OFF + ki * 64;
+        const int sx = 4 * ((ki >> 3) & 1);
+        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&df0);
+        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&df1);
+        *reinterpret_cast<uint2*>(dsr + (((0 + half) ^ sx) << 3)) = make_uint2(w0[0], w0[1]);
+        *reinterpret_cast<uint2*>(dsr + (((2 + half) ^ sx) << 3)) = make_uint2(w0[2], w0[3]);
+        *reinterpret_cast<uint2*>(dsr + (((4 + half) ^ sx) << 3)) = make_uint2(w1[0], w1[1]);
+        *reinterpret_cast<uint2*>(dsr + (((6 + half) ^ sx) << 3)) = make_uint2(w1[2], w1[3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ======================================== step 2: dV, dK, this tile's dQ ========================================
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = s2 ? pf1 : pf0, df = s2 ? df1 : df0;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int lo = tlo + (((4 * dt) ^ tcl) << 4), hi = tlo + 1024 + (((4 * dt) ^ tch) << 4) - lo;
+          const bf16x8 ao = tr_pair(slot + SL_DO + s2 * 2048 + lo, hi);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, pf, dv[dt], 0, 0, 0);
+          const bf16x8 aq = tr_pair(slot + SL_Q + s2 * 2048 + lo, hi);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, df, dk[dt], 0, 0, 0);
+        }
+      }
+      if (wave < 8) {
+        // dQ^T piece: head-dim columns 16 db .. (MFMA rows), queries 16 qb .. (MFMA columns), all keys
+        // lane addresses of k-step 0; a k-step is 32 keys further: + 4096 in the K image, + 2048 in dS^T (the swizzles repeat every 16 keys)
+        const int qb = wave >> 2, db = wave & 3, lr = ln & 15, lg = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
+        const int key_lo = 8 * lg + q4, ca = 2 * db + (p4 >> 1), ub = 4 * qb + p4;
+        const char* ka = smem + kbuf * KIMG + key_lo * 128 + (p4 & 1) * 8;
+        const int ka_lo = (ca ^ swz(key_lo)) << 4, ka_hi = 512 + ((ca ^ swz(key_lo + 4)) << 4);
+        const char* da = smem + DS_OFF + key_lo * 64 + ((ub ^ (4 * (lg & 1))) << 3);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+          const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ka + ks * 4096 + ka_lo));
+          const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ka + ks * 4096 + ka_hi));
+          const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(da + ks * 2048));
+          const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(da + ks * 2048 + 256));
+          bf16x8 af, bfr;
+          af[0] = alo[0]; af[1] = alo[1]; af[2] = alo[2]; af[3] = alo[3]; af[4] = ahi[0]; af[5] = ahi[1]; af[6] = ahi[2]; af[7] = ahi[3];
+          bfr[0] = blo[0]; bfr[1] = blo[1]; bfr[2] = blo[2]; bfr[3] = blo[3]; bfr[4] = bhi[0]; bfr[5] = bhi[1]; bfr[6] = bhi[2]; bfr[7] = bhi[3];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc, 0, 0, 0);
+        }
+        const int q = TQ * t + 16 * qb + lr;
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+        const u32x2 w = {f32x2_to_bf16x2(acc[0] * a.scale, acc[1] * a.scale), f32x2_to_bf16x2(acc[2] * a.scale, acc[3] * a.scale)};
+        __builtin_amdgcn_raw_buffer_store_b64(w, rdq, q < a.Lq ? q * (int)a.ldq * 2 + (16 * db + 4 * lg) * 2 : 0x7fffffff, 0, 0);
+        ++n_cur;
+      }
+      // everything this wave issued before the previous tile has landed; the barrier publishes it (and frees dS^T and the tile's slot)
+      wait_vm_small(n_cur + n_prev);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      n_prev = n_cur;
+      n_cur = 0;
+    }
+    store_item();
+    if (has_next) {
+      my_n = nn;
+      my_head = nh;
+      load_item(kbuf ^ 1);
+    }
+  }
+}
+
+bool ok(const CaseAttnDesc* d) {
+  if (!fwd_ok(d) || d->Lq <= 256) return false;
+  return d->ldo == d->heads * 64 && d->so == d->Lq * d->ldo;
+}
+
+int launch(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, const void* out, const float* lse,
+           const void* dout, float* scratch, void* dq, void* dk, void* dv, hipStream_t s) {
+  const int64_t rows = d->N * d->Lq, nstat = d->N * d->heads * d->Lq;
+  float* negl = scratch;
+  float* negd = scratch + nstat;
+  hipLaunchKernelGGL(stat_kernel, dim3((unsigned)((rows * d->heads + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, lse, negl,
+                     negd, rows, (int)d->heads, (int)d->Lq, 1.f / d->scale);
+  BArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.lddo = d->ldo; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv; a.sdo = d->so;
+  a.negl = negl; a.negd = negd; a.key_valid = key_valid;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.nitems = (int)(d->N * d->heads);
+  a.ntiles = (int)((d->Lq + TQ - 1) / TQ);
+  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_attention_bwd: cannot raise the dynamic LDS limit");
+    int dev = 0, v2 = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v2, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v2 > 0) cus = v2;
+    cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+  }
+  const int grid = a.nitems < cus ? a.nitems : cus;
+  if (a.drop_p > 0.f) hipLaunchKernelGGL(bwd_kernel<true>, dim3(grid), dim3(NT), LDS_B, s, a);
+  else hipLaunchKernelGGL(bwd_kernel<false>, dim3(grid), dim3(NT), LDS_B, s, a);
+  return case_check_launch("case_attention_bwd (resident)");
+}
+
+}  // namespace bwd
 }  // namespace fa64
+
 
 #ifdef FA64_STAMPS
 extern "C" int case_attention_resident_stamps(uint64_t* out) {
@@ -568,4 +1004,12 @@ int case_attention_resident_ok(const CaseAttnDesc* d, const void* q, const void*
 int case_attention_resident_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out,
                                 float* lse, hipStream_t s) {
   return fa64::launch_fwd(d, q, k, v, key_valid, out, lse, s);
+}
+int case_attention_resident_bwd_ok(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                   const void* dq, const void* dk, const void* dv) {
+  return fa64::bwd::ok(d) && ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0;
+}
+int case_attention_resident_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid, const void* out,
+                                const float* lse, const void* dout, float* scratch, void* dq, void* dk, void* dv, hipStream_t s) {
+  return fa64::bwd::launch(d, q, k, v, key_valid, out, lse, dout, scratch, dq, dk, dv, s);
 }

@@ -723,8 +723,8 @@ class AttentionFn(Function):
         dO = dO if dO.is_contiguous() else dO.contiguous()
         bufs = AttentionFn._grad_buffers(q_src, k_src, v_src, heads * d)
         gq, gk, gv = bufs[_src_key(q_src)], bufs[_src_key(k_src)], bufs[_src_key(v_src)]
-        delta = torch.empty(N, heads, Lq, dtype=torch.float32, device=dO.device)
         ad = _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop)
+        delta = torch.empty(A.lib.case_attention_bwd_scratch_floats(ad), dtype=torch.float32, device=dO.device)
         A.call("case_attention_bwd", ad, _ptr(q_src, q_off), _ptr(k_src, k_off), _ptr(v_src, v_off), _ptr(key_valid), _ptr(O), _ptr(lse),
                _ptr(dO), _ptr(delta), _ptr(gq, q_off), _ptr(gk, k_off), _ptr(gv, v_off), _stream())
         out, seen = [], set()
@@ -884,13 +884,14 @@ class AttentionGroupsFn(Function):
         E = heads * d
         dO = dO if dO.is_contiguous() else dO.contiguous()
         dqkv = torch.empty_like(qkv)  # the q, k and v slices of every row are written by the kernels
-        delta = torch.empty_like(lse)
+        delta = torch.empty(2 * lse.numel(), dtype=torch.float32, device=lse.device)  # (case_attention_bwd_scratch_floats of each group)
         lo = 0
         for (r0, N, L), valid, drop in zip(groups, valids, drops):
             view = qkv[r0:r0 + N * L].view(N, L, W)
             ad = _attn_desc(N, heads, L, L, d, view, view, view, False, alpha, drop)
+            assert A.lib.case_attention_bwd_scratch_floats(ad) <= 2 * N * heads * L
             A.call("case_attention_bwd", ad, _ptr(qkv, r0 * W), _ptr(qkv, r0 * W + E), _ptr(qkv, r0 * W + 2 * E), _ptr(valid),
-                   _ptr(O, r0 * E), _ptr(lse, lo), _ptr(dO, r0 * E), _ptr(delta, lo), _ptr(dqkv, r0 * W), _ptr(dqkv, r0 * W + E),
+                   _ptr(O, r0 * E), _ptr(lse, lo), _ptr(dO, r0 * E), _ptr(delta, 2 * lo), _ptr(dqkv, r0 * W), _ptr(dqkv, r0 * W + E),
                    _ptr(dqkv, r0 * W + 2 * E), _stream())
             lo += N * heads * L
         return (dqkv, None, None, None, None) + (None,) * len(valids)

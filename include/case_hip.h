@@ -198,6 +198,9 @@ int case_attention_decode_supported(int64_t head_dim);
 int case_attention_decode(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                           void* out, case_stream_t stream);
 int case_attention_bwd_supported(int64_t head_dim);
+/* floats of scratch case_attention_bwd needs behind `delta` (2 N heads Lq: the resident single-pass backward of head_dim 64, K19,
+ * keeps -lse / scale and -rowsum(dO * O) per query) */
+int64_t case_attention_bwd_scratch_floats(const CaseAttnDesc* d);
 int case_attention_bwd(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                        const void* out, const float* lse, const void* dout, float* delta, void* dq, void* dk, void* dv,
                        case_stream_t stream);

@@ -83,3 +83,74 @@ def test_resident_forward_equals_flash_kernels_with_dropout():
         assert err < 8e-3, err
     finally:
         config.set_dropout(False)
+
+
+def _grads_reference(qkv, valid, h, d, g):
+    N, L, _ = qkv.shape
+    E = h * d
+    r = qkv.detach().float().requires_grad_()
+    q, k, v = r.split(E, dim=-1)
+    qh, kh, vh = [t.reshape(N, L, h, d).transpose(1, 2) for t in (q, k, v)]
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    (p @ vh).transpose(1, 2).reshape(N, L, E).backward(g.float())
+    return r.grad
+
+
+@pytest.mark.parametrize("N,h,L", [(2, 8, 384), (3, 8, 320), (1, 2, 292), (40, 8, 384), (33, 3, 352)])
+def test_resident_backward_matches_reference(N, h, L):
+    """K19, the single-pass backward (dK / dV stationary, dQ through the dS^T tile in LDS): dQ, dK, dV against the f32 autograd of the
+    same bf16 inputs; ragged validity, a sequence without a valid key (zero gradients), workgroups with one and with two items."""
+    ops = _ops()
+    d, E = 64, h * 64
+    g0 = torch.Generator().manual_seed(7 * L + N)
+    qkv = (torch.randn(N, L, 3 * E, generator=g0) * 0.7).to(DEV).to(torch.bfloat16).requires_grad_()
+    g = (torch.randn(N, L, E, generator=g0)).to(DEV).to(torch.bfloat16)
+    valid = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    valid[N - 1, L // 2 + 3:] = False
+    if N > 2:
+        valid[1, 1:] = False
+        valid[2, :] = False
+        valid[N - 2] = (torch.rand(L, generator=g0) > 0.3).to(DEV)
+    ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=valid).backward(g)
+    ref = _grads_reference(qkv, valid, h, d, g)
+    got = qkv.grad.float()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+        err = _rel(got[..., sl], ref[..., sl])
+        assert err < 1.2e-2, (name, err)
+    if N > 2:
+        assert torch.count_nonzero(got[2]) == 0, "no valid key: zero gradients"
+
+
+def test_resident_backward_equals_unfused_path_with_dropout():
+    """Dropout: the backward regenerates the forward's mask (same counter RNG / element index as the unfused GEMM + softmax path)."""
+    from case_rg_amd import _abi, config
+    ops = _ops()
+    N, h, L, d = 5, 8, 384, 64
+    E = h * d
+    g0 = torch.Generator().manual_seed(5)
+    base = (torch.randn(N, L, 3 * E, generator=g0) * 0.7).to(DEV).to(torch.bfloat16)
+    g = (torch.randn(N, L, E, generator=g0)).to(DEV).to(torch.bfloat16)
+    valid = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    valid[3, 200:] = False
+    config.set_dropout(True)
+    try:
+        grads = []
+        for unfused in (False, True):
+            config.manual_seed(11)
+            x = base.clone().requires_grad_()
+            saved = _abi.lib.case_attention_supported
+            try:
+                if unfused:
+                    _abi.lib.case_attention_supported = lambda _d: 0
+                ops.attention(x, x, x, 0, E, 2 * E, h, d, key_valid=valid, p_drop=0.1).backward(g)
+            finally:
+                _abi.lib.case_attention_supported = saved
+            grads.append(x.grad.float())
+        for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+            err = _rel(grads[0][..., sl], grads[1][..., sl])
+            assert err < 2e-2, (name, err)
+    finally:
+        config.set_dropout(False)
