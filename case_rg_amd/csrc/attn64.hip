@@ -570,7 +570,8 @@ int launch_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* 
 // statistics); the K image is double buffered, so the sweep runs on across items; the next item's V fragments are requested into
 // dead registers during the last tile.  Images: 128-byte rows, 16-byte chunk c of row r at slot c ^ f((r >> 1) & 7),
 // f(y) = (y0 << 2) | (y2 << 1) | y1: conflict-free for the ds_read_b128 row fragments, the 32 x 32 transposed fragments AND the
-// 16 x 16 transposed fragments of the dQ product.  dS^T rows are 64 bytes (32 queries): 8-byte unit u of key row k at u ^ 4 ((k >> 3) & 1).
+// 16 x 16 transposed fragments of the dQ product.  dS^T rows are 64 bytes (32 queries): 8-byte unit u of key row k at u ^ ((k >> 1) & 7)
+// (conflict-free for the producers' ds_write_b64 -- sixteen consecutive keys per lane group -- and for the transposed reads).
 // =====================================================================================================================================
 namespace bwd {
 
@@ -645,6 +646,19 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p, int hi_off) {
   return r;
 }
 
+#ifdef FA64_STAMPS
+// diagnostic build only (tools/fa64_stamps.py bwd): workgroup 0, tiles FA64B_T0 .. + 23, every wave: s_memtime at the tile's start, in front of
+// and behind the first barrier, behind the dV / dK products, behind the dQ piece, in front of and behind the second barrier
+#ifndef FA64B_T0
+#define FA64B_T0 14
+#endif
+__device__ uint64_t g_fa64b_stamps[12 * 24 * 7];
+#define FA64B_STAMP(k) { if (blockIdx.x == 0 && T >= FA64B_T0 && T < FA64B_T0 + 24) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+    if (l == 0) g_fa64b_stamps[(wave * 24 + (T - FA64B_T0)) * 7 + (k)] = t_; } }
+#else
+#define FA64B_STAMP(k)
+#endif
+
 template <bool DROP>
 __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
   const int my_items = wper + (wslot < wrem ? 1 : 0);
   if (my_items == 0) return;
   const int pid0 = xfirst + (wslot < wrem ? wslot * (wper + 1) : wrem * (wper + 1) + (wslot - wrem) * wper);
-  const int ntiles = a.ntiles, total_tiles = my_items * ntiles;
+  const int ntiles = a.ntiles;
 
   auto slice = [&](const void* base, int64_t seq_stride, int n, int head) {
     return ((uint64_t)base + (uint64_t)(((int64_t)n * seq_stride + head * 64) * 2)) & 0x0000ffffffffffffull;
@@ -676,74 +690,65 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
   const uint32_t qbytes = (uint32_t)(((int64_t)(a.Lq - 1) * a.ldq + 64) * 2), kbytes = (uint32_t)(((int64_t)(a.Lk - 1) * a.ldk + 64) * 2),
                  obytes = (uint32_t)(((int64_t)(a.Lq - 1) * a.lddo + 64) * 2), sbytes = (uint32_t)(a.Lq * 4);
 
-  // ---- this wave's DMA role: waves 0-3 a Q piece per tile, 4-7 a dO piece, 8-11 the next item's K image (+ 8: the statistics rows)
-  const int prow = 8 * (wave & 3) + (l >> 3);  // row of the 32-row tile (waves 0 .. 7); K image: row 8 piece + (l >> 3)
-  const unsigned vT = (unsigned)(prow * (wave < 4 ? a.ldq : a.lddo) * 2 + (((l & 7) ^ swz(prow)) << 4));
-  const unsigned tstep = (unsigned)(TQ * (wave < 4 ? a.ldq : a.lddo) * 2);
+  // ---- DMA duty: waves 8 .. 11 (they have no dQ piece) issue everything, at the end of a tile's second step: wave 8 + j the Q piece and
+  // the dO piece of tile rows 8 j .. 8 j + 7 and two pieces of the next item's K image per tile (first six tiles of an item); wave 8 also
+  // the statistics rows, wave 9 the dropout row keys.  All per-item addresses advance by increments (head fastest inside the range).
+  const int prow = 8 * (wave & 3) + (l >> 3);  // row of the 32-row tile
+  const unsigned vTq = (unsigned)(prow * a.ldq * 2 + (((l & 7) ^ swz(prow)) << 4)), vTo = (unsigned)(prow * a.lddo * 2 + (((l & 7) ^ swz(prow)) << 4));
+  const unsigned qtstep = (unsigned)(TQ * a.ldq * 2), otstep = (unsigned)(TQ * a.lddo * 2);
   // K image piece p = rows 8 p .. 8 p + 7; the pieces a wave issues all have the parity of the wave (wave + 12 i in the prologue, wave - 8 + 4 j
   // in the sweep), and the swizzle of row 8 p + r depends on p through its parity only
   const int krow = l >> 3;
   const unsigned vKi = (unsigned)(krow * a.ldk * 2 + (((l & 7) ^ swz(8 * (wave & 1) + krow)) << 4));
-  // ---- stream state: (sequence, head) of the item being computed and of the item the DMA stream (3 tiles ahead) is in
-  int my_n = pid0 / a.heads, my_head = pid0 - my_n * a.heads;
-  int dn = my_n, dh = my_head, dtile = 0, ditem = 0;  // DMA stream position
+  const unsigned kpiece = (unsigned)(8 * a.ldk * 2);
+
+  int my_n = pid0 / a.heads, my_head = pid0 - my_n * a.heads;  // the item being computed
+  // the DMA stream runs LOOK tiles ahead: its item's head index, tile, and the base addresses of the operands in that item
+  int dh = my_head, dtile = 0, ditem = 0;
+  const int64_t seqstep_q = (a.sq - (int64_t)(a.heads - 1) * 64) * 2, seqstep_o = (a.sdo - (int64_t)(a.heads - 1) * 64) * 2;
+  uint64_t qbase = slice(a.q, a.sq, my_n, my_head), obase = slice(a.dout, a.sdo, my_n, my_head);
+  uint64_t soff = (uint64_t)(((int64_t)my_n * a.heads + my_head) * a.Lq) * 4ull;  // byte offset of the item's statistics rows; row index for the keys
   int n_cur = 0, n_prev = 0;
-  auto advance_item = [&](int& n, int& h) {
-    if (++h == a.heads) {
-      h = 0;
-      ++n;
-    }
-  };
-  // the pieces of stream tile (ditem, dtile) into ring slot `sl`
+  // the pieces of the stream's tile into ring slot `sl` (waves 8 .. 11), then the stream moves on by one tile
   auto issue_tile = [&](int sl) {
     const unsigned sb = lds0 + RING_OFF + sl * SLOT_B;
-    if (wave < 4) {
-      dma16(desc(slice(a.q, a.sq, dn, dh), qbytes), vT, (unsigned)dtile * tstep, sb + SL_Q + (wave & 3) * 1024);
-      ++n_cur;
-    } else if (wave < 8) {
-      dma16(desc(slice(a.dout, a.sdo, dn, dh), obytes), vT, (unsigned)dtile * tstep, sb + SL_DO + (wave & 3) * 1024);
-      ++n_cur;
-    } else if (wave == 8) {
-      const uint64_t off = (uint64_t)(((int64_t)dn * a.heads + dh) * a.Lq) * 4ull;
-      dma4(desc(((uint64_t)a.negl + off) & 0x0000ffffffffffffull, sbytes), (unsigned)(dtile * 128 + 4 * l), sb + SL_NL);
-      dma4(desc(((uint64_t)a.negd + off) & 0x0000ffffffffffffull, sbytes), (unsigned)(dtile * 128 + 4 * l), sb + SL_ND);
+    if (ditem < my_items) {
+      dma16(desc(qbase, qbytes), vTq, (unsigned)dtile * qtstep, sb + SL_Q + (wave & 3) * 1024);
+      dma16(desc(obase, obytes), vTo, (unsigned)dtile * otstep, sb + SL_DO + (wave & 3) * 1024);
       n_cur += 2;
+      if (wave == 8) {
+        dma4(desc(((uint64_t)a.negl + soff) & 0x0000ffffffffffffull, sbytes), (unsigned)(dtile * 128 + 4 * l), sb + SL_NL);
+        dma4(desc(((uint64_t)a.negd + soff) & 0x0000ffffffffffffull, sbytes), (unsigned)(dtile * 128 + 4 * l), sb + SL_ND);
+        n_cur += 2;
+      } else if (DROP && wave == 9) {  // the dropout row keys of the tile's queries
+        if (l < 32) {
+          const uint32_t rk = rng_row_key(a.seed, a.offset + (soff >> 2) + (uint64_t)(dtile * TQ + l));
+          *reinterpret_cast<uint32_t*>(smem + RING_OFF + sl * SLOT_B + SL_RK + 4 * l) = rk;
+        }
+      }
     }
-    if (DROP && wave == 9 && l < 32) {  // the dropout row keys of the tile's queries
-      const uint32_t rk = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)dn * a.heads + dh) * a.Lq + dtile * TQ + l));
-      *reinterpret_cast<uint32_t*>(smem + RING_OFF + sl * SLOT_B + SL_RK + 4 * l) = rk;
-    }
-  };
-  auto advance_stream = [&]() {
     if (++dtile == ntiles) {
       dtile = 0;
       ++ditem;
-      advance_item(dn, dh);
+      const bool w = dh + 1 == a.heads;
+      qbase += (uint64_t)(w ? seqstep_q : 128);
+      obase += (uint64_t)(w ? seqstep_o : 128);
+      dh = w ? 0 : dh + 1;
+      soff += (uint64_t)a.Lq * 4ull;
     }
-  };
-  // K image pieces of item (n, h) into buffer `buf`: pieces kw, kw + 4, .. (kw = wave - 8), two per call
-  auto issue_kimg = [&](int n, int h, int buf, int first_piece) {
-    const i32x4 rk = desc(slice(a.k, a.sk, n, h), kbytes);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pc = first_piece + 4 * i;
-      dma16(rk, vKi, (unsigned)(pc * 8 * a.ldk * 2), lds0 + buf * KIMG + pc * 1024);
-    }
-    n_cur += 2;
   };
 
   // ---- prologue: the first item's K image (4 pieces per wave), tiles 0 .. 2
+  uint64_t kcur = slice(a.k, a.sk, my_n, my_head);
   {
-    const i32x4 rk = desc(slice(a.k, a.sk, my_n, my_head), kbytes);
+    const i32x4 rk = desc(kcur, kbytes);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pc = wave + 12 * i;
-      dma16(rk, vKi, (unsigned)(pc * 8 * a.ldk * 2), lds0 + pc * 1024);
+      dma16(rk, vKi, (unsigned)pc * kpiece, lds0 + pc * 1024);
     }
-    for (int i = 0; i < LOOK; ++i) {
-      if (ditem < my_items) issue_tile(i);
-      advance_stream();
-    }
+    if (wave >= 8)
+      for (int i = 0; i < LOOK; ++i) issue_tile(i);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -757,22 +762,25 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
   bf16x8 kf[4], vf[4];
   f32x16 dk[2], dv[2];
   bool key_ok = true, keys_all_ok = true;
+  uint32_t kbyte = 1u;
   const uint32_t jc1 = ((uint32_t)ki >> 1) * RNG_C1, field_shift = 16u * ((uint32_t)ki & 1u);
+  const int vrow = ki < a.Lk ? ki : a.Lk - 1;  // clamped: such a key is masked
 
-  auto load_item = [&](int buf) {  // stationary fragments of item (my_n, my_head): K rows from its image, V rows from memory
-    const char* kb = smem + buf * KIMG + k0 * 128 + r32 * 128;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kb + (((2 * s + half) ^ swz(r32)) << 4));
-    const int row = ki < a.Lk ? ki : a.Lk - 1;  // clamped: such a key is masked
-    const bf16_t* vp = a.v + (int64_t)my_n * a.sv + my_head * 64 + (int64_t)row * a.ldv + 8 * half;
+  // V fragments and the validity byte of this lane's key in item (n, head): plain loads, issued a whole step before their first use
+  auto request_stationary = [&](int n, int head) {
+    const bf16_t* vp = a.v + (int64_t)n * a.sv + head * 64 + (int64_t)vrow * a.ldv + 8 * half;
 #pragma unroll
     for (int s = 0; s < 4; ++s) vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
-    key_ok = ki < a.Lk && (!a.key_valid || a.key_valid[(int64_t)my_n * a.Lk + row] != 0);
+    kbyte = a.key_valid ? (uint32_t)a.key_valid[(int64_t)n * a.Lk + vrow] : 1u;
+  };
+  auto take_stationary = [&](int buf) {  // K fragments from the item's image; the validity flags
+    if constexpr (!DROP) {  // (the dropout instantiation has no registers left: it reads the K fragments from the image every tile)
+      const char* kb = smem + buf * KIMG + k0 * 128 + r32 * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kb + (((2 * s + half) ^ swz(r32)) << 4));
+    }
+    key_ok = ki < a.Lk && kbyte != 0u;
     keys_all_ok = __all(key_ok);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dk[dt][e] = dv[dt][e] = 0.f;
   };
   auto store_item = [&]() {  // dK = scale dK^T^T, dV = dV^T^T as 16-byte pieces (K18's store_item); rows beyond Lk fall outside the descriptors
     int lane_ = l;
@@ -805,13 +813,16 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
     n_cur += 8;
   };
 
-  load_item(0);
+  request_stationary(my_n, my_head);
+  take_stationary(0);
+  const int64_t seqstep_k = (a.sk - (int64_t)(a.heads - 1) * 64) * 2;
   int T = 0;
   for (int item = 0; item < my_items; ++item) {
     const int kbuf = item & 1;
     const bool has_next = item + 1 < my_items;
-    int nn = my_n, nh = my_head;
-    advance_item(nn, nh);
+    const bool wrap = my_head + 1 == a.heads;
+    const int nn = wrap ? my_n + 1 : my_n, nh = wrap ? 0 : my_head + 1;
+    const uint64_t knext = kcur + (uint64_t)(wrap ? seqstep_k : 128);
     const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dq + (int64_t)my_n * a.sq + my_head * 64), 0, (int)qbytes, 0x00020000);
     for (int t = 0; t < ntiles; ++t, ++T) {
       const char* slot = smem + RING_OFF + (T & 3) * SLOT_B;
@@ -826,9 +837,7 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
       const int tq = (ln & 15) >> 2, tp = ln & 3, dhalf = (ln >> 4) & 1, trow = 4 * half + tq;
       const int tlo = trow * 128 + (tp & 1) * 8, tcl = (2 * dhalf + (tp >> 1)) ^ swz(trow), tch = (2 * dhalf + (tp >> 1)) ^ swz(trow + 8);
       // ======================================== step 1: S, dP, the exponentials, dS ========================================
-      if (T + LOOK < total_tiles) issue_tile((T + LOOK) & 3);
-      advance_stream();
-      if (has_next && wave >= 8 && t < 6) issue_kimg(nn, nh, kbuf ^ 1, (wave - 8) + 8 * t);
+      FA64B_STAMP(0)
       f32x16 st, dp;
       {
         const float* nl = reinterpret_cast<const float*>(slot + SL_NL) + 4 * half;
@@ -840,8 +849,6 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
           if (!DROP) {
             const f32x4 y = *reinterpret_cast<const f32x4*>(nd + 8 * g);
             dp[4 * g] = y[0]; dp[4 * g + 1] = y[1]; dp[4 * g + 2] = y[2]; dp[4 * g + 3] = y[3];
-          } else {
-            dp[4 * g] = dp[4 * g + 1] = dp[4 * g + 2] = dp[4 * g + 3] = 0.f;
           }
         }
         if (TQ * t + TQ > a.Lq) {  // rows beyond Lq (their statistics read as zeros): p = 0
@@ -849,11 +856,13 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
           for (int e = 0; e < 16; ++e)
             if (TQ * t + (e & 3) + 8 * (e >> 2) + 4 * half >= a.Lq) st[e] = -INFINITY;
         }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int ro = rbase + (((2 * s) ^ rsw) << 4);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + SL_Q + ro), kf[s], st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + SL_DO + ro), vf[s], dp, 0, 0, 0);
+          const bf16x8 kfs = DROP ? *reinterpret_cast<const bf16x8*>(smem + kbuf * KIMG + k0 * 128 + ro) : kf[s];
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + SL_Q + ro), kfs, st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + SL_DO + ro), vf[s], (DROP && s == 0) ? zero : dp, 0, 0, 0);
         }
       }
       // p = 2^(scale2 S'); the dropped-out probabilities (for dV) and dS / scale (the factor goes on the finished dK and dQ)
@@ -880,13 +889,14 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
             dp[e] = pr * fmaf(dp[e], kp, d4[i]);  // P (keep / (1 - p) dP - delta)
             st[e] = pr * kp;
           }
+          __builtin_amdgcn_sched_barrier(0);  // four rows at a time (interleaving all sixteen hashes spills)
         }
       }
       const bf16x8 pf0 = pack_acc(st, 0), pf1 = pack_acc(st, 1), df0 = pack_acc(dp, 0), df1 = pack_acc(dp, 1);
       {
         // dS^T[key][query]: this lane's key row, four queries (8 bytes) per unit 2 g + half
-        char* dsr = smem + DS_OFF + ki * 64;
-        const int sx = 4 * ((ki >> 3) & 1);
+        char* dsr = smem + DS_OFF + (k0 + r32) * 64;
+        const int sx = (r32 >> 1) & 7;  // (k0 is a multiple of 32)
         const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&df0);
         const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&df1);
         *reinterpret_cast<uint2*>(dsr + (((0 + half) ^ sx) << 3)) = make_uint2(w0[0], w0[1]);
@@ -894,8 +904,18 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
         *reinterpret_cast<uint2*>(dsr + (((4 + half) ^ sx) << 3)) = make_uint2(w1[0], w1[1]);
         *reinterpret_cast<uint2*>(dsr + (((6 + half) ^ sx) << 3)) = make_uint2(w1[2], w1[3]);
       }
+      FA64B_STAMP(1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      FA64B_STAMP(2)
+      // the next item's V fragments and validity byte (K and V fragments are dead from here to the end of the item: the loads fly
+      // under this tile's second step and the gradient stores)
+#ifndef FA64B_LATE_STATIONARY
+      if (t == ntiles - 1 && has_next) {
+        request_stationary(nn, nh);
+        n_cur += a.key_valid ? 5 : 4;
+      }
+#endif
       // ======================================== step 2: dV, dK, this tile's dQ ========================================
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -904,26 +924,37 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
         for (int dt = 0; dt < 2; ++dt) {
           const int lo = tlo + (((4 * dt) ^ tcl) << 4), hi = tlo + 1024 + (((4 * dt) ^ tch) << 4) - lo;
           const bf16x8 ao = tr_pair(slot + SL_DO + s2 * 2048 + lo, hi);
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, pf, dv[dt], 0, 0, 0);
           const bf16x8 aq = tr_pair(slot + SL_Q + s2 * 2048 + lo, hi);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, df, dk[dt], 0, 0, 0);
+          if (t == 0 && s2 == 0) {  // an item's first products start the accumulators (no zero fill)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, pf, zero, 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, df, zero, 0, 0, 0);
+          } else {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, df, dk[dt], 0, 0, 0);
+          }
         }
       }
+#ifdef FA64_STAMPS
+      asm volatile("" : "+v"(dk[0]), "+v"(dk[1]), "+v"(dv[0]), "+v"(dv[1]));
+#endif
+      FA64B_STAMP(3)
       if (wave < 8) {
-        // dQ^T piece: head-dim columns 16 db .. (MFMA rows), queries 16 qb .. (MFMA columns), all keys
+        // dQ^T piece: head-dim columns 16 db .. (MFMA rows), queries 16 qb .. (MFMA columns), all keys.
         // lane addresses of k-step 0; a k-step is 32 keys further: + 4096 in the K image, + 2048 in dS^T (the swizzles repeat every 16 keys)
         const int qb = wave >> 2, db = wave & 3, lr = ln & 15, lg = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
         const int key_lo = 8 * lg + q4, ca = 2 * db + (p4 >> 1), ub = 4 * qb + p4;
         const char* ka = smem + kbuf * KIMG + key_lo * 128 + (p4 & 1) * 8;
         const int ka_lo = (ca ^ swz(key_lo)) << 4, ka_hi = 512 + ((ca ^ swz(key_lo + 4)) << 4);
-        const char* da = smem + DS_OFF + key_lo * 64 + ((ub ^ (4 * (lg & 1))) << 3);
+        const char* da = smem + DS_OFF + key_lo * 64;
+        const int da_lo = (ub ^ ((key_lo >> 1) & 7)) << 3, da_hi = 256 + ((ub ^ (((key_lo + 4) >> 1) & 7)) << 3);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 12; ++ks) {
           const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ka + ks * 4096 + ka_lo));
           const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ka + ks * 4096 + ka_hi));
-          const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(da + ks * 2048));
-          const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(da + ks * 2048 + 256));
+          const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(da + ks * 2048 + da_lo));
+          const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(da + ks * 2048 + da_hi));
           bf16x8 af, bfr;
           af[0] = alo[0]; af[1] = alo[1]; af[2] = alo[2]; af[3] = alo[3]; af[4] = ahi[0]; af[5] = ahi[1]; af[6] = ahi[2]; af[7] = ahi[3];
           bfr[0] = blo[0]; bfr[1] = blo[1]; bfr[2] = blo[2]; bfr[3] = blo[3]; bfr[4] = bhi[0]; bfr[5] = bhi[1]; bfr[6] = bhi[2]; bfr[7] = bhi[3];
@@ -933,20 +964,37 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
         const u32x2 w = {f32x2_to_bf16x2(acc[0] * a.scale, acc[1] * a.scale), f32x2_to_bf16x2(acc[2] * a.scale, acc[3] * a.scale)};
         __builtin_amdgcn_raw_buffer_store_b64(w, rdq, q < a.Lq ? q * (int)a.ldq * 2 + (16 * db + 4 * lg) * 2 : 0x7fffffff, 0, 0);
-        ++n_cur;
+      } else {
+        // the DMA pieces of tile T + 3 (its slot held tile T - 1: free since that tile's second barrier) and two pieces of the next
+        // item's K image: (wave - 8) + 4 (2 t + i)
+        issue_tile((T + LOOK) & 3);
+        if (has_next && t < 6) {
+          const i32x4 rk = desc(knext, kbytes);
+          const int pc = (wave - 8) + 8 * t;
+          dma16(rk, vKi, (unsigned)pc * kpiece, lds0 + (kbuf ^ 1) * KIMG + pc * 1024);
+          dma16(rk, vKi, (unsigned)(pc + 4) * kpiece, lds0 + (kbuf ^ 1) * KIMG + (pc + 4) * 1024);
+          n_cur += 2;
+        }
       }
-      // everything this wave issued before the previous tile has landed; the barrier publishes it (and frees dS^T and the tile's slot)
-      wait_vm_small(n_cur + n_prev);
+      FA64B_STAMP(4)
+      // everything a DMA wave issued before the previous tile has landed (counted wait); the barrier publishes it
+      if (wave >= 8) wait_vm_small(n_cur + n_prev);
+      FA64B_STAMP(5)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      FA64B_STAMP(6)
       n_prev = n_cur;
       n_cur = 0;
     }
+#ifdef FA64B_LATE_STATIONARY
+    if (has_next) request_stationary(nn, nh);
+#endif
     store_item();
     if (has_next) {
       my_n = nn;
       my_head = nh;
-      load_item(kbuf ^ 1);
+      kcur = knext;
+      take_stationary(kbuf ^ 1);
     }
   }
 }
@@ -994,6 +1042,9 @@ int launch(const CaseAttnDesc* d, const void* q, const void* k, const void* v, c
 #ifdef FA64_STAMPS
 extern "C" int case_attention_resident_stamps(uint64_t* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(fa64::g_fa64_stamps), sizeof(fa64::g_fa64_stamps)) == hipSuccess ? 0 : -1;
+}
+extern "C" int case_attention_resident_bwd_stamps(uint64_t* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fa64::bwd::g_fa64b_stamps), sizeof(fa64::bwd::g_fa64b_stamps)) == hipSuccess ? 0 : -1;
 }
 #endif
 
