@@ -171,7 +171,13 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
         record_error(name, mode, "ln_top1_prob", err, 1.0)
         assert err <= 1.0, "ln(top-1 probability): %.2e" % err
     assert same.any(), "no answer of the batch equals the reference's"
-    assert np.array_equal(to_np(rec["top1_id"])[same], golden["top1_id"][same])
+    # the teacher-forced top-1 ids: exact in fp32; in bf16 wherever the reference's own top-1 / top-2 log ratio is above the bar (the
+    # greedy loop and the teacher-forced pass of ONE bf16 model already disagree with each other on a near-tie: round 4, row 0 of
+    # prod_masque_test, ids 13413 / 13699)
+    decisive = np.ones_like(logit_margin, dtype=bool) if mode == "fp32" else logit_margin > bars["logit_bar"]
+    pick = same[:, None] & decisive
+    record_error(name, mode, "teacher_forced_top1_positions_checked_of_%d" % want.size, float(pick.sum()), float(want.size))
+    assert np.array_equal(to_np(rec["top1_id"])[pick], golden["top1_id"][pick])
     if mode == "bf16_auto":
         assert m.calls.get("case_attention_decode", 0) > 0, "attn_decode64_kernel did not run"
         assert 64 in m.tiles, "no GEMM ran on the 64x64 small-problem tiling"
