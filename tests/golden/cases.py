@@ -694,8 +694,22 @@ def case_cfg5_dec_layer_long_memory(ns, dev):
     return out
 
 
+def case_cfg5_case_train(ns, dev):
+    """Model-level cfg 5 geometry: CaSE at d_model 768 -- head_dim 96 in the encoder / H-wide blocks / decoder and 480
+    in the 5H blocks, Interaction at Lp 512, the decoder's cross-attention over a 2 x 512-token memory -- one query, two passages."""
+    v2i, i2v = make_vocab(PROD_V)
+    m = _mod(ns.CaSE(4, 40, i2v, v2i, 768), 231, dev)
+    b = synth_batch(1, 2, 512, 64, 40, PROD_V, seed=232, model="case", filler_passage=False)
+    b = {k: v.to(dev) for k, v in b.items()}
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_se": losses[1].reshape(1), "loss_rg": losses[2].reshape(1)})
+    rec.update(_model_grads(m, losses, CASE_GRAD_NAMES, strided=True))
+    return rec
+
+
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
-PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory")
+PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory", "cfg5_case_train")
 PROD_TEST_CASES = ("prod_case_test", "prod_masque_test")  # greedy decoding at production geometry
 PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too

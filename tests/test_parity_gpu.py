@@ -311,7 +311,7 @@ def test_rouge_l_of_greedy_answers_within_0p2_of_the_oracle(ns):
     with torch.no_grad():
         ans = ref_model(dict(batch), method="test")["answer"]
     want = eval_rouge_l([" ".join(w) for w in oracle.to_sentence(ans.tolist(), i2v)], [[t] for t in truth])
-    scores, same = {}, {}
+    scores, same, prefix = {}, {}, {}
     for dt in (torch.float32, torch.bfloat16):
         case_rg_amd.set_compute_dtype(dt)
         try:
@@ -320,11 +320,19 @@ def test_rouge_l_of_greedy_answers_within_0p2_of_the_oracle(ns):
                 got = model({k: v.cuda() for k, v in batch.items()}, method="test")["answer"]
             scores[str(dt)] = eval_rouge_l([" ".join(w) for w in model.to_sentence(None, got)], [[t] for t in truth])
             same[str(dt)] = float((got.cpu() == ans).all(dim=1).float().mean())
+            prefix[str(dt)] = float(((got.cpu() == ans).long().cumprod(dim=1).sum(dim=1).float() / T).mean())  # common prefix / T
         finally:
             case_rg_amd.set_compute_dtype(torch.float32)
     record_error("rouge_l_synthetic_dev", "fp32", "rouge_l_points_vs_oracle", abs(scores["torch.float32"] - want), 0.2)
     record_error("rouge_l_synthetic_dev", "bf16_auto", "rouge_l_points_vs_oracle", abs(scores["torch.bfloat16"] - want), 0.2)
-    record_error("rouge_l_synthetic_dev", "bf16_auto", "fraction_of_answers_identical_to_oracle", 1.0 - same["torch.bfloat16"], 0.25)
+    record_error("rouge_l_synthetic_dev", "fp32", "fraction_of_answers_differing_from_oracle", 1.0 - same["torch.float32"], 0.03)
+    record_error("rouge_l_synthetic_dev", "bf16_auto", "fraction_of_answers_differing_from_oracle", 1.0 - same["torch.bfloat16"], 0.5)
+    record_error("rouge_l_synthetic_dev", "bf16_auto", "mean_common_prefix_fraction_short_of_1", 1.0 - prefix["torch.bfloat16"], 0.3)
+    # asserted (round 3 only recorded them): fp32 decodes the oracle's answers; in bf16 one near-tie anywhere changes an answer from
+    # there on (12 tokens, margins of a random model), so the bar is on whole answers AND on the prefix that agrees
+    assert same["torch.float32"] >= 0.97, "fp32: %.3f of the answers equal the oracle's" % same["torch.float32"]
+    assert same["torch.bfloat16"] >= 0.5, "bf16: %.3f of the answers equal the oracle's" % same["torch.bfloat16"]
+    assert prefix["torch.bfloat16"] >= 0.7, "bf16: mean common prefix %.3f of T" % prefix["torch.bfloat16"]
     assert want > 0.0, "degenerate dev set"
     assert len(set(map(tuple, ans.tolist()))) > 8, "the oracle's answers collapsed to a few strings"
     assert abs(scores["torch.float32"] - want) <= 0.2, "fp32: ROUGE-L %.2f vs oracle %.2f" % (scores["torch.float32"], want)

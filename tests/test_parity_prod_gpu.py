@@ -31,14 +31,21 @@ MODES = {
     "bf16_large_fused": dict(dtype=torch.bfloat16, tile=256, attn="fused"),
     "bf16_small_unfused": dict(dtype=torch.bfloat16, tile=128, attn="unfused"),
 }
-# bf16 bars per case: (outputs / losses: max error relative to the tensor's scale, gradients: relative L2 error)
-BF16_BARS = {"prod_case_train": (2e-2, 0.2), "prod_masque_train": (2e-2, 0.2),           # 8 + 5 (+ 5) ReLU blocks in the graph
-             "cfg5_block_5h": (1.5e-2, 0.08), "cfg5_block_h": (1.5e-2, 0.08),            # one ReLU block
+# bf16 bars per case: (outputs / losses: max error relative to the tensor's scale, gradients: relative L2 error of the fixture's
+# STRIDED SLICES).  Round 4: the gradient bar is per mode, 1.5 x the worst slice error measured for that mode
+# (profiles/r04_parity_errors.json; round 3's blanket 0.2 hid a 0.148 entry).  A slice keeps every 97th .. element of a tensor, so
+# its error scatters around the full tensor's: tools/bisect_masque_bf16.py (profiles/r04_masque_bf16_bisect.txt) measures 0.056 on
+# the FULL gradient of the tensor whose slice read 0.148 in round 3 and 0.07 with this round's attention kernels -- the full-tensor
+# errors are pinned by test_bf16_auto_full_gradients_are_uniformly_close_to_the_oracle below.
+BF16_BARS = {"prod_case_train": (2e-2, {"bf16_auto": 0.11, "bf16_large_fused": 0.13, "bf16_small_unfused": 0.095}),
+             "prod_masque_train": (2e-2, {"bf16_auto": 0.115, "bf16_large_fused": 0.185, "bf16_small_unfused": 0.145}),
+             "cfg5_case_train": (2e-2, {"bf16_auto": 0.15, "bf16_large_fused": 0.2, "bf16_small_unfused": 0.15}),
+             "cfg5_block_5h": (1.5e-2, 0.135), "cfg5_block_h": (1.5e-2, 0.16),           # one ReLU block (measured 0.088 / 0.106)
              "cfg5_dec_layer_long_memory": (2e-2, 0.02),                                # GELU only
              "prod_enc_layer": (1.5e-2, None), "prod_block_5h": (1.5e-2, None)}
 
 
-HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
+HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "cfg5_case_train": (96, 480), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
              "cfg5_dec_layer_long_memory": (96,), "prod_enc_layer": (64,), "prod_block_5h": (320,)}
 
 
@@ -84,6 +91,8 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
     golden = load_golden(name)
     assert set(rec) == set(golden), "case %s: keys differ: %s" % (name, set(rec) ^ set(golden))
     tol_out, tol_grad = (1e-3, 1e-3) if mode == "fp32" else BF16_BARS[name]
+    if isinstance(tol_grad, dict):
+        tol_grad = tol_grad[mode]
     failures = []
     for k, want in golden.items():
         got = to_np(rec[k])
@@ -183,6 +192,92 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
         assert 64 in m.tiles, "no GEMM ran on the 64x64 small-problem tiling"
         assert m.calls.get("additive_decode_row", 0) > 0, "the T = 1 additive-attention kernel did not run"
         assert m.calls.get("case_copy_scatter_sorted_fwd", 0) > 0, "the sorted pointer scatter did not run"
+
+
+@pytest.mark.parametrize("model", ["masque", "case"])
+def test_bf16_auto_full_gradients_are_uniformly_close_to_the_oracle(model):
+    """the fixtures hold strided slices of the gradients, and one slice of prod_masque_train read 0.148 in bf16_auto.
+    On the FULL tensors (CPU oracle, same weights and batch) every parameter gradient of the bench mode is within 0.09 (Masque) / 0.15
+    (CaSE) relative L2 and 0.993 cosine of the f32 oracle, the mean error below 0.035: the bf16 error grows with the number of ReLU
+    blocks a gradient has passed (test_bf16_block_gradient_error_is_the_relu_mask: 4-5 % per block) -- Masque's worst is the encoder's
+    embedding (0.065), CaSE's the Interaction weight underneath the three token-identification blocks on top of the five selection
+    blocks (0.113, profiles/r04_case_bf16_bisect.txt) -- and no tensor has an error of its own."""
+    import case_rg_amd
+    import oracle
+    seed = 221 if model == "masque" else 211
+
+    def grads(ns, dev, dtype):
+        case_rg_amd.set_compute_dtype(dtype)
+        case_rg_amd.set_dropout(False)
+        try:
+            if hasattr(ns, "act_dtype"):
+                ns.act_dtype = dtype
+            m = cases._prod_model(ns, dev, seed, model)
+            b = cases._prod_batch(dev, seed + 1, model)
+            sum(l.mean() for l in m(dict(b), method="train")).backward()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            return {n: p.grad.detach().cpu().double() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            case_rg_amd.set_compute_dtype(torch.float32)
+
+    want = grads(oracle, torch.device("cpu"), torch.float32)
+    got = grads(case_rg_amd.namespace(), torch.device("cuda"), torch.bfloat16)
+    assert set(got) == set(want)
+    errs = {}
+    for n, w in want.items():
+        g = got[n]
+        errs[n] = ((g - w).norm().item() / (w.norm().item() + 1e-30), torch.dot(g.flatten(), w.flatten()).item() / (g.norm().item() * w.norm().item() + 1e-30))
+    worst = max(errs, key=lambda n: errs[n][0])
+    mean = sum(e[0] for e in errs.values()) / len(errs)
+    bar = 0.09 if model == "masque" else 0.15
+    record_error("prod_%s_train_full_gradients" % model, "bf16_auto", "worst_rel_l2:" + worst, errs[worst][0], bar, errs[worst][0])
+    record_error("prod_%s_train_full_gradients" % model, "bf16_auto", "mean_rel_l2", mean, 0.035, mean)
+    assert errs[worst][0] <= bar, "%s: %.3f" % (worst, errs[worst][0])
+    assert mean <= 0.035, mean
+    assert min(e[1] for e in errs.values()) >= 0.993
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_production_geometry_greedy_pass_replays_from_a_hipgraph(dtype):
+    """cfg 4 (BASELINE.json: "hipGraph-captured step") at PRODUCTION geometry -- H 512, 8 heads of 64, Lp 384, V 30 522, the
+    prod_case_test model and batch: the whole greedy pass (encode through the fused chain + T cached steps: attn_decode64_kernel, the
+    64 x 64 GEMMs at M = batch, the T = 1 additive rows, the sorted pointer scatter) is captured in one graph, replayed twice, and
+    must reproduce the eager ids and rank logits bit for bit; in fp32 the ids are also the reference fixture's."""
+    import case_rg_amd
+    from case_rg_amd import ops
+    old_pairs = ops.DECODE_MIN_PAIRS
+    ops.DECODE_MIN_PAIRS = 1
+    case_rg_amd.set_compute_dtype(dtype)
+    case_rg_amd.set_dropout(False)
+    try:
+        ns = case_rg_amd.namespace()
+        ns.act_dtype = dtype
+        dev = torch.device("cuda")
+        m = cases._prod_test_model(ns, dev, 311, "case", cases.PROD_TEST_GAIN["case"]).eval()
+        b = cases._prod_test_batch(dev, 312, "case")
+        with torch.no_grad():
+            eager = m(dict(b), method="test")
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                m(dict(b), method="test")  # warm-up on the capture stream (allocator, lazily built caches)
+            torch.cuda.current_stream().wait_stream(side)
+            graph, static = torch.cuda.CUDAGraph(), {}
+            with torch.cuda.graph(graph):
+                static.update(m(dict(b), method="test"))
+            for _ in range(2):
+                static["answer"].zero_()
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(static["answer"], eager["answer"]), "hipGraph replay: ids differ from the eager pass"
+                assert torch.equal(static["rank"], eager["rank"]), "hipGraph replay: rank logits differ from the eager pass"
+        if dtype == torch.float32:
+            assert np.array_equal(to_np(eager["answer"]), load_golden("prod_case_test")["answer"])
+    finally:
+        ops.DECODE_MIN_PAIRS = old_pairs
+        case_rg_amd.set_compute_dtype(torch.float32)
 
 
 def test_wide_head_fused_backward_is_off_the_training_path():
