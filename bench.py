@@ -568,6 +568,15 @@ def main():
         "last_losses": [round(x, 4) for x in losses],
         "world_size": dist.get_world_size() if dist.is_initialized() else 1, "rank_ms_per_step": rank_ms,
     }
+    if trainer.sync is not None and trainer.sync.active:
+        # how long the compute stream stood still in GradSync.finish() per step (HIP events around the waits, this rank; the timed
+        # steps only): the part of the gradient all-reduce that backward did not hide
+        from case_rg_amd import _abi as _A
+        out["data_parallel"] = {"allreduce_exposed_ms": round(trainer.sync.exposed_ms(last=a.steps), 3), "buckets": len(trainer.sync.buckets),
+                                "bucket_mb": round(max(b["flat"].numel() for b in trainer.sync.buckets) * 4 / 2 ** 20, 1),
+                                "gradient_mb": round(sum(b["flat"].numel() for b in trainer.sync.buckets) * 4 / 2 ** 20, 1),
+                                "wire_dtype": "bf16" if trainer.sync.comm_dtype is not None else "f32",
+                                "reserved_cus": _A.lib.case_get_reserved_cus()}
     if a.mode == "cfg5":
         out["metric"] += ", cfg 5 long context"
         if rank == 0 and not a.no_roofline:

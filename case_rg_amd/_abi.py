@@ -12,7 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CASE_HIP_LIB: another build of the same library (A/B measurements of kernel variants); there is still no non-HIP path
 LIB_PATH = os.environ.get("CASE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcase_hip.so")
 
+ABI_VERSION = 400  # include/case_hip.h CASE_ABI_VERSION this binding was written against
 F32, BF16 = 0, 1
+WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK = 1, 2, 3, 4
+FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS = (
+    1 << i for i in range(8))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -98,6 +102,7 @@ SIGNATURES = {
     "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
     "case_encoder_chain_pack": [ptr, ptr, ptr, ptr, ptr, ptr],
     "case_encoder_chain": [C.POINTER(EncoderChainDesc)] + [ptr] * 14,
+    "case_set_reserved_cus": [i32],
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
     "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
 }
@@ -109,6 +114,11 @@ def _load():
             "case_rg_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C case_rg_amd/csrc`). There is no CPU or eager fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.case_version.restype = C.c_int
+    if lib.case_version() != ABI_VERSION:
+        # a layout-only change (CaseOptTensor grew in round 3) would otherwise mis-stride tables silently
+        raise ImportError("case_rg_amd: %s is ABI generation %d, this package binds %d -- rebuild it (make -C case_rg_amd/csrc)"
+                          % (LIB_PATH, lib.case_version(), ABI_VERSION))
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = args
@@ -119,7 +129,14 @@ def _load():
     lib.case_encoder_chain_packed_bytes.argtypes = []
     lib.case_attention_bwd_scratch_floats.restype = C.c_int64
     lib.case_attention_bwd_scratch_floats.argtypes = [C.POINTER(AttnDesc)]
-    lib.case_version.restype = C.c_int
+    lib.case_abi_features.restype = C.c_uint32
+    lib.case_abi_features.argtypes = []
+    lib.case_get_reserved_cus.restype = C.c_int
+    lib.case_get_reserved_cus.argtypes = []
+    lib.case_sizeof_opt_tensor.restype = C.c_int
+    lib.case_sizeof_opt_tensor.argtypes = []
+    lib.case_workspace_bytes.restype = C.c_int64
+    lib.case_workspace_bytes.argtypes = [i32, ptr, i64]
     lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()
     lib.case_gemm_tile_for.argtypes = [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr]
     lib.case_last_error.restype = C.c_char_p

@@ -55,6 +55,7 @@ class CumulativeTrainer(object):
                      if dist.is_available() and dist.is_initialized() else None)
         self.ema = EMA(self.model, ema_rate)
         self.ema.register()
+        self._loss_host = None
 
     def train_batch(self, epoch, data, method, optimizer, scheduler=None):
         self.accumulation_count += 1
@@ -67,7 +68,16 @@ class CumulativeTrainer(object):
         else:
             parts = loss.mean().reshape(1)
         (parts.sum() / self.accumulation_steps).backward()
-        closs = parts.detach().cpu().tolist()
+        # the losses go to a pinned buffer without blocking; the host waits for them only AFTER the all-reduce wait and the
+        # optimizer kernels are enqueued (round 3 drained the device here, in the middle of the step, before enqueueing them)
+        host, done = None, None
+        if parts.is_cuda:
+            if self._loss_host is None or self._loss_host.numel() != parts.numel():
+                self._loss_host = torch.empty(parts.numel(), dtype=torch.float32).pin_memory()
+            host = self._loss_host
+            host.copy_(parts.detach().float(), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
         if boundary:
             if self.sync is not None:
                 self.sync.finish()
@@ -81,7 +91,10 @@ class CumulativeTrainer(object):
             if scheduler is not None:
                 scheduler.step()
             optimizer.zero_grad()
-        return closs
+        if host is None:
+            return parts.detach().cpu().tolist()
+        done.synchronize()
+        return host.tolist()
 
     def serialize(self, epoch, output_path):
         if self.local_rank not in (0, None):

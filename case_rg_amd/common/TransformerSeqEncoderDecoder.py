@@ -97,9 +97,9 @@ class TransformerSeqEncoder(nn.Module):
 class PointerDecoderCore(nn.Module):
     """Shared machinery of the three pointer-generator decoders."""
 
-    def _build(self, num_memories, num_layers, nhead, vocab, H, query_width, emb_matrix=None):
+    def _build(self, num_memories, num_layers, nhead, vocab, H, query_width, emb_matrix=None, max_len=1000):
         self.tgt_vocab_size, self.num_layers, self.hidden_size = vocab, num_layers, H
-        self.embedding = _embedding(vocab, H, emb_matrix=emb_matrix)
+        self.embedding = _embedding(vocab, H, max_len=max_len, emb_matrix=emb_matrix)
         layer = TransformerDecoderLayer(H, nhead=nhead, dim_feedforward=H, dropout=0.1, activation='gelu')
         self.decs = nn.ModuleList([TransformerDecoder(layer, num_layers=num_layers, norm=None) for _ in range(num_memories)])
         self.attns = nn.ModuleList([BilinearAttention(query_width, H, H) for _ in range(num_memories)])
@@ -229,7 +229,10 @@ class TransformerSeqDecoder(PointerDecoderCore):
     def __init__(self, num_memories, num_layers, nhead, tgt_vocab_size, hidden_size, emb_matrix=None):
         super().__init__()
         H = hidden_size
-        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H, emb_matrix=emb_matrix)
+        # the reference's generic decoder builds its position table with max_len = 100 when a pre-trained embedding matrix is given
+        # (common/TransformerSeqEncoderDecoder.py:57; 1000 otherwise, :55): ``pe`` is a persistent buffer, so a checkpoint of that
+        # configuration only loads strictly into the same shape
+        self._build(num_memories, num_layers, nhead, tgt_vocab_size, H, H, emb_matrix=emb_matrix, max_len=100 if emb_matrix is not None else 1000)
         self.norm = nn.LayerNorm(H)
         self.gen = nn.Sequential(nn.Linear(2 * H, H), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))
         self.mix = nn.Linear(H + num_memories * H, num_memories + 1)

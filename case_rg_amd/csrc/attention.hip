@@ -936,6 +936,18 @@ extern "C" int case_attention_splitkv_workspace(const CaseAttnDesc* d, int32_t k
   return 0;
 }
 
+extern "C" int64_t case_encoder_chain_packed_bytes(void);
+extern "C" int64_t case_workspace_bytes(int32_t kind, const void* desc, int64_t arg) {
+  const CaseAttnDesc* d = (const CaseAttnDesc*)desc;
+  switch (kind) {
+    case CASE_WS_ATTENTION_SPLITKV: return d && arg >= 1 ? splitkv_bytes(d, (int32_t)arg) : (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: bad argument");
+    case CASE_WS_ATTENTION_BWD: return d ? case_attention_bwd_scratch_floats(d) * 4 : (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: null descriptor");
+    case CASE_WS_OPTIM_SUMSQ: return arg >= 0 ? arg * 4 : (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: bad argument");
+    case CASE_WS_ENCODER_CHAIN_PACK: return case_encoder_chain_packed_bytes();
+    default: return (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: unknown kind %d", (int)kind);
+  }
+}
+
 extern "C" int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                                           void* out, float* lse, void* workspace, int64_t workspace_bytes, int32_t ksplit,
                                           case_stream_t stream) {

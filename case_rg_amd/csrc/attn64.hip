@@ -537,16 +537,14 @@ int launch_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* 
   a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse; a.key_valid = key_valid;
   a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.nitems = (int)(d->N * d->heads);
   a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
-  static int cus = 0;
-  if (!cus) {
+  static bool attr = false;
+  if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return case_set_error(CASE_E_LAUNCH, "case_attention_fwd: cannot raise the dynamic LDS limit");
-    int dev = 0, v2 = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v2, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v2 > 0) cus = v2;
-    cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+    attr = true;
   }
+  const int cus = case_persistent_cus();
   const int grid = a.nitems < cus ? a.nitems : cus;
   if (a.drop_p > 0.f) hipLaunchKernelGGL(fwd_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
   else hipLaunchKernelGGL(fwd_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
@@ -1019,16 +1017,14 @@ int launch(const CaseAttnDesc* d, const void* q, const void* k, const void* v, c
   a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.nitems = (int)(d->N * d->heads);
   a.ntiles = (int)((d->Lq + TQ - 1) / TQ);
   a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
-  static int cus = 0;
-  if (!cus) {
+  static bool attr = false;
+  if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess)
       return case_set_error(CASE_E_LAUNCH, "case_attention_bwd: cannot raise the dynamic LDS limit");
-    int dev = 0, v2 = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v2, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v2 > 0) cus = v2;
-    cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+    attr = true;
   }
+  const int cus = case_persistent_cus();
   const int grid = a.nitems < cus ? a.nitems : cus;
   if (a.drop_p > 0.f) hipLaunchKernelGGL(bwd_kernel<true>, dim3(grid), dim3(NT), LDS_B, s, a);
   else hipLaunchKernelGGL(bwd_kernel<false>, dim3(grid), dim3(NT), LDS_B, s, a);

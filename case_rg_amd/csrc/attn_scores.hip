@@ -398,15 +398,14 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
 
 template <bool BWD>
 int launch(const Args& a, hipStream_t s) {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scores_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-      hipSuccess)
-    return case_set_error(CASE_E_LAUNCH, "case_attention_scores: cannot raise the dynamic LDS limit");
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  static bool attr = false;  // (once per instantiation: the attribute call is not free on the launch path)
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scores_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_attention_scores: cannot raise the dynamic LDS limit");
+    attr = true;
   }
-  cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;  // whole XCD rounds; one workgroup per CU (132 KiB of LDS each)
+  const int cus = case_persistent_cus();  // whole XCD rounds; one workgroup per CU (132 KiB of LDS each)
   hipLaunchKernelGGL((scores_kernel<BWD>), dim3(a.nblk < cus ? a.nblk : cus), dim3(NTHR), LDS_BYTES, s, a);
   return case_check_launch(BWD ? "case_attention_scores_bwd" : "case_attention_scores_fwd");
 }
@@ -587,14 +586,13 @@ __global__ __launch_bounds__(NTHR) void rc_gemm_kernel(const GArgs g) {
 
 template <bool AK>
 int launch_rc(const GArgs& a, hipStream_t s) {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rc_gemm_kernel<AK>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
-    return case_set_error(CASE_E_LAUNCH, "case_attention_product: cannot raise the dynamic LDS limit");
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rc_gemm_kernel<AK>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_attention_product: cannot raise the dynamic LDS limit");
+    attr = true;
   }
-  cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+  const int cus = case_persistent_cus();
   hipLaunchKernelGGL((rc_gemm_kernel<AK>), dim3(a.nblk < cus ? a.nblk : cus), dim3(NTHR), G_LDS, s, a);
   return case_check_launch("case_attention_product");
 }

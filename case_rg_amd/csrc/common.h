@@ -9,6 +9,8 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 
 int case_set_error(int code, const char* fmt, ...);
 int case_check_launch(const char* what);
+int case_device_cus();      // compute units of the current device (cached)
+int case_persistent_cus();  // ... minus the reserved ones, rounded down to whole XCD rounds: the grid of the persistent kernels
 
 #define CASE_REQUIRE(cond, ...)                          \
   do {                                                   \

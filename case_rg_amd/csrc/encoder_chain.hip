@@ -526,9 +526,13 @@ template <int VARIANT>
 int launch(const Args& a, int cus, hipStream_t s) {
   const int ntiles = (int)((a.M + TOK - 1) / TOK);
   const dim3 grid(ntiles < cus ? ntiles : cus), block(NTHR);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-      hipSuccess)
-    return case_set_error(CASE_E_LAUNCH, "case_encoder_chain: cannot reserve %d bytes of LDS", LDS_BYTES);
+  static bool attr = false;  // (once per instantiation)
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_encoder_chain: cannot reserve %d bytes of LDS", LDS_BYTES);
+    attr = true;
+  }
   hipLaunchKernelGGL((chain_kernel<VARIANT>), grid, block, LDS_BYTES, s, a);
   return case_check_launch("case_encoder_chain");
 }
@@ -577,11 +581,7 @@ extern "C" int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_i
   a.M = d->rows;
   a.eps2 = d->eps_ln2;
   a.eps1n = d->eps_ln1_next;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = case_persistent_cus();
   switch (d->variant) {
     case enc_chain::VAR_FULL: return enc_chain::launch<enc_chain::VAR_FULL>(a, cus, (hipStream_t)stream);
     case enc_chain::VAR_TAIL: return enc_chain::launch<enc_chain::VAR_TAIL>(a, cus, (hipStream_t)stream);

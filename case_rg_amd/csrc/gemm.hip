@@ -54,16 +54,7 @@ struct Args {
 namespace {
 constexpr int BM = 128, BN = 128, ROWB = 128;
 
-int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = n > 0 ? n : 256;
-  }
-  return cus;
-}
+int device_cus() { return case_device_cus(); }
 }  // namespace
 
 namespace {
@@ -182,7 +173,7 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
   const int epi = d->epilogue;
   hipStream_t s = (hipStream_t)stream;
   if (tile == 256) {
-    const int cus = device_cus();
+    const int cus = case_persistent_cus();
     if (d->out_dtype == CASE_BF16) return gemm_t8w::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
     if (epi & CASE_EPI_ATOMIC) return gemm_t8w::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
     return gemm_t8w::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);

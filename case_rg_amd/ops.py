@@ -50,12 +50,17 @@ def _u8(mask):
 _cast_cache = {}
 
 
+PARAM_EPOCH = 0
+
+
 def invalidate_param_cache():
     """Forget every cached low-precision parameter copy (and the fragment-ordered weight packs of the fused encoder chain).  ``_version`` does not move when a parameter is rewritten through
     ``.data`` (``p.data = t``, ``p.data.copy_()``, ``xavier_uniform_(p.data)``, ``dist.broadcast(p.data)``), so the code paths
     that do that -- ``EMA.apply_shadow`` / ``restore``, ``GradSync.broadcast_parameters``, ``init_params`` -- call this."""
     _cast_cache.clear()
     _chain_packs.clear()
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1  # (modules that keep packed copies of their own parameters compare this counter: common/Highway.py)
 
 
 def seed_param_cache(p, low):
@@ -745,11 +750,8 @@ class AttentionFn(Function):
     def _product(mat, b_src, b_off, out, c_off, heads, d, M, Kc, transposed, alpha=1.0):
         """out[n, row, head, :] = alpha * sum_k A[n, head][row, k] b[n, k, head, :], A = mat [N, heads, La, Lb] or its transpose (K17's
         row-complete product kernel at head_dim 320); False when the shape is outside its scope (the caller runs case_gemm)."""
-        if not SCORES_FUSED or d != 320 or mat.dtype != torch.bfloat16 or Kc % 64 or Kc < 128:
+        if not SCORES_FUSED or mat.dtype != torch.bfloat16:
             return False
-        for t, off in ((b_src, b_off), (out, c_off)):
-            if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:
-                return False
         N, _, La, Lb = mat.shape
         pd = A.AttnProductDesc()
         pd.N, pd.heads, pd.M, pd.Kc, pd.head_dim = N, heads, M, Kc, d
@@ -757,6 +759,16 @@ class AttentionFn(Function):
         pd.ldb, pd.sb_seq, pd.sb_head = b_src.shape[2], b_src.shape[1] * b_src.shape[2], d
         pd.ldc, pd.sc_seq, pd.sc_head = out.shape[2], out.shape[1] * out.shape[2], d
         pd.a_transposed, pd.alpha = int(transposed), alpha
+        # the library's own shape query, then a mirror of case_attention_product's stride / alignment / 32-bit-offset requirements:
+        # outside them the caller runs case_gemm instead of getting a RuntimeError
+        if not A.lib.case_attention_product_supported(pd):
+            return False
+        strides = (pd.lda, pd.ldb, pd.ldc, pd.sa_seq, pd.sa_head, pd.sb_seq, pd.sb_head, pd.sc_seq, pd.sc_head)
+        if any(v % 8 for v in strides) or b_off % 8 or c_off % 8 or any(t.data_ptr() % 16 for t in (mat, b_src, out)):
+            return False
+        a_rows = Kc if transposed else M
+        if pd.lda < (M if transposed else Kc) or a_rows * pd.lda * 2 >= 1 << 31 or Kc * pd.ldb * 2 >= 1 << 31 or (M + 127) * pd.ldc * 2 >= 1 << 31:
+            return False
         A.call("case_attention_product", pd, _ptr(mat), _ptr(b_src, b_off), _ptr(out, c_off), _stream())
         return True
 

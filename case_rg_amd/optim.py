@@ -20,6 +20,10 @@ class _Entry(C.Structure):
                 ("p_bf16", C.c_void_p), ("numel", C.c_int64), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
 
 
+if C.sizeof(_Entry) != A.lib.case_sizeof_opt_tensor():
+    raise ImportError("case_rg_amd.optim: CaseOptTensor is %d bytes in libcase_hip.so, %d here" % (A.lib.case_sizeof_opt_tensor(), C.sizeof(_Entry)))
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, low_precision=None):
         """``low_precision``: dtype (torch.bfloat16) of operand copies to refresh in the same pass, or None."""
@@ -28,7 +32,11 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.low_precision = low_precision
         self._chunks = {}
-        self._table = (None, None)  # (host bytes, device copy): re-uploaded only when a pointer moved
+        # the entry table carries the step-dependent Adam scalars, so its bytes change every step: it goes up through a ring of PINNED
+        # staging buffers with a non-blocking copy into ONE persistent device table (no pageable upload, no new device tensor per step)
+        self._table = None   # device uint8
+        self._stage = []     # [(pinned uint8, event of its last upload)]
+        self._stage_next = 0
         self._low = {}  # id(parameter) -> its operand copy, rewritten in place by every step
         self._norm_ws = None  # f32 [1 + chunks]: squared gradient norm + its per-chunk partials
 
@@ -58,10 +66,10 @@ class FusedAdam(torch.optim.Optimizer):
             # EMA.update() does for every trainable parameter (common/EMA.py:13-18)
             params = [p for p in group["params"] if p.grad is not None]
             idle = [p for p in group["params"] if p.grad is None and p.requires_grad and id(p) in shadow_of]
-            if not params:
-                continue
-            dev = params[0].device
-            if not params[0].is_cuda:
+            if not params and not idle:
+                continue  # (a group without any gradient still moves its EMA shadows: the idle entries below)
+            dev = (params or idle)[0].device
+            if not (params or idle)[0].is_cuda:
                 raise RuntimeError("case_rg_amd.optim.FusedAdam runs on the GPU only; there is no CPU path")
             beta1, beta2 = group["betas"]
             lr = float(group["lr"])
@@ -91,9 +99,19 @@ class FusedAdam(torch.optim.Optimizer):
             for j, p in enumerate(idle):
                 entries[len(params) + j] = _Entry(p.data_ptr(), 0, 0, 0, shadow_of[id(p)].data_ptr(), 0, p.numel(), 0.0, 1.0)
             raw = bytes(entries)
-            if self._table[0] != raw or self._table[1].device != dev:
-                self._table = (raw, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
-            table = self._table[1]
+            if self._table is None or self._table.numel() < len(raw) or self._table.device != dev:
+                self._table = torch.empty(max(len(raw), 4096), dtype=torch.uint8, device=dev)
+                self._stage = [(torch.empty(self._table.numel(), dtype=torch.uint8).pin_memory(), None) for _ in range(3)]
+            stage, ev = self._stage[self._stage_next]
+            if ev is not None:
+                ev.synchronize()  # its upload of three steps ago (long done: the host never runs three steps ahead of the device)
+            stage[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self._table[:len(raw)].copy_(stage[:len(raw)], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage[self._stage_next] = (stage, ev)
+            self._stage_next = (self._stage_next + 1) % len(self._stage)
+            table = self._table
             chunks = self._chunk_list([p.numel() for p in params + idle], dev)
             stream = torch.cuda.current_stream().cuda_stream
             sumsq = None

@@ -8,14 +8,20 @@ bucket as soon as it is complete, so communication of the decoder / block gradie
 backward (which is > 90 % of its time).  ``finish()`` waits, averages and scatters the buckets back.
 Batch items never interact in forward, so there is no other collective on the path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None, force=False):
+    def __init__(self, model, bucket_mb=64, process_group=None, force=False, reserve_cus=None, comm_dtype=None):
         """``force`` keeps the bucket / hook / collective machinery active on a one-rank group (used by the GPU test that
-        drives the RCCL path on a single device)."""
+        drives the RCCL path on a single device).
+        ``reserve_cus``: compute units the persistent kernels (256 x 256 GEMM, K16 .. K19) leave free while the group is active, so
+        that RCCL's kernels can be resident beside them and the all-reduce really overlaps backward (default: environment
+        CASE_DP_RESERVE_CUS, else 8 = one per XCD; 0 switches it off).  ``comm_dtype``: torch.bfloat16 halves the bytes on the wire
+        (gradients are rounded once before the sum; default f32, environment CASE_DP_BF16=1 selects bf16)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -24,8 +30,16 @@ class GradSync:
         self._armed = False
         self._next = 0  # index of the next bucket to launch (in-order collectives)
         self.active = dist.is_initialized() and (self.world > 1 or force)
+        self.exposed = []  # (start, end) event pairs around finish()'s waits on the compute stream: exposed_ms()
+        self.comm_dtype = comm_dtype if comm_dtype is not None else (torch.bfloat16 if os.environ.get("CASE_DP_BF16") == "1" else None)
         if not self.active:
             return
+        if reserve_cus is None:
+            reserve_cus = int(os.environ.get("CASE_DP_RESERVE_CUS", "8"))
+        self.reserved_cus = reserve_cus if self.params and self.params[0].is_cuda else 0
+        if self.reserved_cus:
+            from . import _abi
+            _abi.call("case_set_reserved_cus", int(self.reserved_cus))
         cap = int(bucket_mb * (1 << 20) // 4)
         cur, cur_n = [], 0
         for p in reversed(self.params):
@@ -91,7 +105,13 @@ class GradSync:
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)
-        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.comm_dtype is not None:
+            if b.get("wire") is None:
+                b["wire"] = torch.empty(b["flat"].numel(), dtype=self.comm_dtype, device=b["flat"].device)
+            b["wire"].copy_(b["flat"])
+            b["work"] = dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Flush the buckets whose hooks did not all fire (zeros stand in for the missing gradients), wait, average, and make
@@ -99,10 +119,29 @@ class GradSync:
         if not self.active or not self._armed:
             return
         self._launch_ready(flush=True)
+        timed = self.buckets and self.buckets[0]["flat"].is_cuda
+        if timed:  # how long the compute stream stands still for the collectives = the communication backward did not hide
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for b in self.buckets:
             b["work"].wait()
+        if timed:
+            e1.record()
+            self.exposed.append((e0, e1))
+            del self.exposed[:-64]
+        for b in self.buckets:
+            if self.comm_dtype is not None:
+                b["flat"].copy_(b["wire"])
             b["flat"].div_(self.world)
             for (p, _, _), view in zip(b["items"], b["views"]):
                 p.grad = view
             b["work"], b["pending"] = None, len(b["items"])
         self._next = 0
+
+    def exposed_ms(self, last=None):
+        """Mean time per step the compute stream waited in finish() (synchronises on the recorded events)."""
+        pairs = self.exposed[-last:] if last else self.exposed
+        if not pairs:
+            return 0.0
+        pairs[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)

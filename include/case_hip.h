@@ -40,8 +40,41 @@ enum {
   CASE_E_LAUNCH = -3       /* hipGetLastError() after enqueue */
 };
 
+/* ABI generation.  case_version() returns the CASE_ABI_VERSION the library was built from; a binder compares it with the header it was
+ * written against (case_rg_amd/_abi.py refuses any other library).  Bumped with every struct or signature change:
+ *   100 round 1 | 200 round 2 (case_gemm_dw_bias, decode, optimizer) | 300 round 3 (CaseOptTensor 56 -> 64 bytes, K16 / K17)
+ *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs). */
+#define CASE_ABI_VERSION 400
 int case_version(void);
+/* what the build contains, as a bit mask */
+enum {
+  CASE_FEAT_GEMM_256 = 1u << 0,        /* 256 x 256 eight-wave GEMM tiling (+ case_gemm_dw_bias) */
+  CASE_FEAT_GEMM_SMALL = 1u << 1,      /* 64 x 64 small-problem tiling */
+  CASE_FEAT_ENCODER_CHAIN = 1u << 2,   /* K16 case_encoder_chain */
+  CASE_FEAT_ATTN_SCORES = 1u << 3,     /* K17 case_attention_scores_* / case_attention_product */
+  CASE_FEAT_ATTN_DECODE = 1u << 4,     /* case_attention_decode */
+  CASE_FEAT_OPTIM = 1u << 5,           /* K15 case_optim_* */
+  CASE_FEAT_ATTN_RESIDENT = 1u << 6,   /* K18 / K19 behind case_attention_fwd / _bwd */
+  CASE_FEAT_RESERVED_CUS = 1u << 7     /* case_set_reserved_cus */
+};
+uint32_t case_abi_features(void);
 const char* case_last_error(void);
+
+/* Compute units the persistent kernels (256 x 256 GEMM, K16 .. K19) leave free -- the ONE piece of mutable library configuration:
+ * with world_size > 1 RCCL's kernels must be resident beside them for the gradient all-reduce to overlap backward
+ * (common/CumulativeTrainer.py:45-47).  0 .. 128, rounded so that the grids stay whole XCD rounds; initial value from the environment
+ * variable CASE_RESERVE_CUS (default 0). */
+int case_set_reserved_cus(int n);
+int case_get_reserved_cus(void);
+
+/* Caller-owned scratch of the entry points that need one, in bytes:
+ *   CASE_WS_ATTENTION_SPLITKV  desc = CaseAttnDesc*, arg = ksplit     (workspace of case_attention_fwd_splitkv)
+ *   CASE_WS_ATTENTION_BWD      desc = CaseAttnDesc*                   (the `delta` argument of case_attention_bwd)
+ *   CASE_WS_OPTIM_SUMSQ        arg = nchunks                          (the `partials` argument of case_optim_sumsq)
+ *   CASE_WS_ENCODER_CHAIN_PACK                                        (the packed weights of case_encoder_chain_pack)
+ * negative = CASE_E_ARG. */
+typedef enum { CASE_WS_ATTENTION_SPLITKV = 1, CASE_WS_ATTENTION_BWD = 2, CASE_WS_OPTIM_SUMSQ = 3, CASE_WS_ENCODER_CHAIN_PACK = 4 } case_workspace_kind_t;
+int64_t case_workspace_bytes(int32_t kind, const void* desc, int64_t arg);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  strided-batched GEMM on MFMA:   C = epilogue(alpha * op(A) op(B))
@@ -364,6 +397,7 @@ typedef struct {
   float bc2_sqrt;
 } CaseOptTensor;
 int case_optim_chunk_elems(void);
+int case_sizeof_opt_tensor(void); /* sizeof(CaseOptTensor) as the library was built: a binder checks its own layout against it */
 int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* partials, float* sumsq,
                      case_stream_t stream);
 int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,

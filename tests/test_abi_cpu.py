@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "case_hip.h")
 def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"\b(?:int|const char\*)\s+(case_\w+)\s*\(", text))
+    return set(re.findall(r"\b(?:int|int64_t|uint32_t|const char\*)\s+(case_\w+)\s*\(", text))
 
 
 def test_library_exports_every_declared_symbol():
@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_table_matches_header():
     from case_rg_amd import _abi
-    assert set(_abi.SIGNATURES) | {"case_version", "case_last_error", "case_gemm_tile_for", "case_optim_chunk_elems"} == _declared()
+    other = {"case_version", "case_last_error", "case_gemm_tile_for", "case_optim_chunk_elems", "case_abi_features", "case_get_reserved_cus",
+             "case_sizeof_opt_tensor", "case_workspace_bytes", "case_attention_bwd_scratch_floats", "case_encoder_chain_packed_bytes"}
+    assert set(_abi.SIGNATURES) | other == _declared()
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for name, args in _abi.SIGNATURES.items():
         proto = re.search(r"\b%s\s*\((.*?)\);" % name, text, flags=re.S).group(1)
@@ -52,8 +54,39 @@ def test_struct_layouts_match_header_field_order():
 
 def test_version_and_error_string():
     from case_rg_amd import _abi
-    assert _abi.lib.case_version() >= 100
+    header = int(re.search(r"#define CASE_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert _abi.lib.case_version() == header == _abi.ABI_VERSION, "library, header and binding must be one ABI generation"
     assert isinstance(_abi.lib.case_last_error(), bytes)
+
+
+def test_abi_generation_features_and_workspace_queries():
+    """Round 4 (ADVICE): an out-of-tree binder can tell ABI generations apart (case_version == CASE_ABI_VERSION,
+    feature mask), check its struct layouts (case_sizeof_opt_tensor) and size every caller-owned scratch (case_workspace_bytes)."""
+    import ctypes as C
+    from case_rg_amd import _abi, optim
+    feats = _abi.lib.case_abi_features()
+    for bit in (_abi.FEAT_GEMM_256, _abi.FEAT_GEMM_SMALL, _abi.FEAT_ENCODER_CHAIN, _abi.FEAT_ATTN_SCORES, _abi.FEAT_ATTN_DECODE, _abi.FEAT_OPTIM,
+                _abi.FEAT_ATTN_RESIDENT, _abi.FEAT_RESERVED_CUS):
+        assert feats & bit
+    assert _abi.lib.case_sizeof_opt_tensor() == C.sizeof(optim._Entry) == 64
+    d = _abi.AttnDesc()
+    d.N, d.heads, d.Lq, d.Lk, d.head_dim = 3, 8, 40, 4096, 64
+    need = _abi.i64(0)
+    _abi.call("case_attention_splitkv_workspace", d, 4, need)
+    assert _abi.lib.case_workspace_bytes(_abi.WS_ATTENTION_SPLITKV, C.byref(d), 4) == need.value == 4 * 3 * 8 * 40 * 66 * 4
+    assert _abi.lib.case_workspace_bytes(_abi.WS_ATTENTION_BWD, C.byref(d), 0) == _abi.lib.case_attention_bwd_scratch_floats(d) * 4 == 2 * 3 * 8 * 40 * 4
+    assert _abi.lib.case_workspace_bytes(_abi.WS_OPTIM_SUMSQ, None, 17) == 68
+    assert _abi.lib.case_workspace_bytes(_abi.WS_ENCODER_CHAIN_PACK, None, 0) == _abi.lib.case_encoder_chain_packed_bytes()
+    assert _abi.lib.case_workspace_bytes(99, None, 0) < 0 and b"unknown kind" in _abi.lib.case_last_error()
+    # reserved compute units: the one mutable setting of the library
+    keep = _abi.lib.case_get_reserved_cus()
+    try:
+        _abi.call("case_set_reserved_cus", 16)
+        assert _abi.lib.case_get_reserved_cus() == 16
+        with pytest.raises(RuntimeError, match="out of range"):
+            _abi.call("case_set_reserved_cus", 1000)
+    finally:
+        _abi.call("case_set_reserved_cus", keep)
 
 
 def test_argument_validation_happens_before_any_launch():

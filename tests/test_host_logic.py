@@ -200,12 +200,14 @@ def test_special_id_cache_follows_the_vocabulary_object():
 
 def test_bench_gpus_flag_starts_the_ranks_itself_or_fails_loudly():
     """`python bench.py --gpus N` outside torch.distributed.run must not silently run one rank: it spawns the N
-    ranks as a child process -- or, when the node has fewer GPUs (here: none), says so; and a WORLD_SIZE that contradicts --gpus is
-    refused.  (The spawn itself is rehearsed on the GPU box with CASE_BENCH_FORCE_SPAWN=1 --gpus 1.)"""
+    ranks as a child process -- or, when the node has fewer GPUs, says so; and a WORLD_SIZE that contradicts --gpus is refused.
+    Host-independent: more GPUs than any node has are asked for, and the devices are hidden from the child, so the
+    "node shows N GPU(s)" branch is taken on every host.  (The spawn itself is rehearsed on the GPU box with CASE_BENCH_FORCE_SPAWN=1.)"""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
-    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout) and "GPU(s)" in (r.stderr + r.stdout), r.stderr[-300:]
+    env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4096"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 4096" in (r.stderr + r.stdout) and "GPU(s)" in (r.stderr + r.stdout), r.stderr[-300:]
     env["WORLD_SIZE"] = "4"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout), r.stderr[-300:]
