@@ -233,9 +233,19 @@ def roofline_cross_attention(a, device):
         torch.cuda.synchronize()
     secs = e0.elapsed_time(e1) / iters * 1e-3
     nbytes = N * S * 2 * E * 2
+    traffic, traffic_src = None, None  # PMC bytes of the split-KV forward launch alone (tools/cfg5_stream.py under two rocprofv3 passes)
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_cfg5stream_pmc.json")))
+    if files:
+        try:
+            with open(files[-1]) as fh:
+                traffic = json.load(fh)["kernels"]["fa_fwd_kernel"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + os.path.basename(files[-1])
+        except (OSError, ValueError, KeyError):
+            pass
     return {"bound": "hbm", "kernel": "fa_fwd_kernel<96, split-KV> + fa_combine_kernel<96> (decoder cross-attention, S = %d)" % S,
             "achieved": round(nbytes / secs / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / secs / 8e12, 4),
-            "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(secs * 1e3, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(secs * 1e3, 4),
             "launches_per_step": "8 forward (2 stacks x 4 layers; the query-memory stack has S = %d)" % a.query_len}
 
 
@@ -243,7 +253,7 @@ def _thread_candidates(cores):
     return sorted({c for c in (8, 16, 32, cores) if 0 < c <= cores})
 
 
-def cpu_baseline(a):
+def cpu_baseline(a, max_passages=None):
     """The CPU oracle (fp32 port of the reference, oracle/) on this host: training steps (fwd + bwd + clip + Adam) at batch 1 of
     the same shapes, ALL P passages.  The thread count matters more than the core count (128 threads ran 4.5x SLOWER than 8 in
     round 2: oversubscribed intra-op pools), so the leg first probes one step at 8 / 16 / 32 / all threads on a 4-passage sample,
@@ -272,9 +282,10 @@ def cpu_baseline(a):
 
     host = torch.get_num_threads()
     Ps = min(4, a.passages)
+    Pf = a.passages if max_passages is None else min(a.passages, max_passages)  # cfg 5 (40 x 512, H 768): a bounded sample of the passages
     probe = synth_batch(1, Ps, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
-    full = synth_batch(1, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
-    tok_probe, tok_full = a.query_len + Ps * a.passage_len, a.query_len + a.passages * a.passage_len
+    full = synth_batch(1, Pf, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=7, ragged=False, model=a.model)
+    tok_probe, tok_full = a.query_len + Ps * a.passage_len, a.query_len + Pf * a.passage_len
     by_threads = {}
     torch.set_num_threads(min(8, host))
     step(probe)  # warm-up (allocator, thread pool, first-call overheads)
@@ -293,7 +304,7 @@ def cpu_baseline(a):
             "sample": "fp32 CPU oracle (decomposed Interaction: faster than the reference's own formulation), batch 1 x %d passages x %d "
                       "tokens, fwd+bwd+clip+Adam; thread count probed on a %d-passage step (tokens/s by threads in by_threads), then 1 "
                       "warm-up + median of 3 full steps at the fastest setting, %d threads (%.1f s each)" % (
-                          a.passages, a.passage_len, Ps, best, med)}
+                          Pf, a.passage_len, Ps, best, med)}
 
 
 def cpu_baseline_decode(a):
@@ -593,6 +604,8 @@ def main():
         out["north_star"] = north_star_point(a, device)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "train":
         out["cpu_baseline"] = cpu_baseline(a)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "cfg5":
+        out["cpu_baseline"] = cpu_baseline(a, max_passages=8)  # 8 of the 40 passages: ~20 s of CPU work per step
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
