@@ -14,9 +14,9 @@ LIB_PATH = os.environ.get("CASE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcas
 
 ABI_VERSION = 400  # include/case_hip.h CASE_ABI_VERSION this binding was written against
 F32, BF16 = 0, 1
-WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK = 1, 2, 3, 4
-FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS = (
-    1 << i for i in range(8))
+WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
+(FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
+ FEAT_GEMM_DW_SLABS) = (1 << i for i in range(9))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -53,6 +53,7 @@ class AttnProductDesc(C.Structure):
 SIGNATURES = {
     "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_gemm_dw_bias": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr],
+    "case_gemm_dw_slabs": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, i64, ptr],
     "case_embed_pos_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
     "case_embed_pos_bwd": [ptr, ptr, ptr, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
     "case_scale_add_rows": [ptr, ptr, ptr, i64, i64, i64, f32, i32, ptr],
@@ -135,6 +136,8 @@ def _load():
     lib.case_get_reserved_cus.argtypes = []
     lib.case_sizeof_opt_tensor.restype = C.c_int
     lib.case_sizeof_opt_tensor.argtypes = []
+    lib.case_gemm_dw_slab_bytes.restype = C.c_int64
+    lib.case_gemm_dw_slab_bytes.argtypes = [C.POINTER(GemmDesc)]
     lib.case_workspace_bytes.restype = C.c_int64
     lib.case_workspace_bytes.argtypes = [i32, ptr, i64]
     lib.case_gemm_tile_for.restype = C.c_int  # 128 / 256 or a negative code: not routed through check()

@@ -937,6 +937,7 @@ extern "C" int case_attention_splitkv_workspace(const CaseAttnDesc* d, int32_t k
 }
 
 extern "C" int64_t case_encoder_chain_packed_bytes(void);
+extern "C" int64_t case_gemm_dw_slab_bytes(const CaseGemmDesc* d);
 extern "C" int64_t case_workspace_bytes(int32_t kind, const void* desc, int64_t arg) {
   const CaseAttnDesc* d = (const CaseAttnDesc*)desc;
   switch (kind) {
@@ -944,6 +945,7 @@ extern "C" int64_t case_workspace_bytes(int32_t kind, const void* desc, int64_t 
     case CASE_WS_ATTENTION_BWD: return d ? case_attention_bwd_scratch_floats(d) * 4 : (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: null descriptor");
     case CASE_WS_OPTIM_SUMSQ: return arg >= 0 ? arg * 4 : (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: bad argument");
     case CASE_WS_ENCODER_CHAIN_PACK: return case_encoder_chain_packed_bytes();
+    case CASE_WS_GEMM_DW_SLABS: return desc ? case_gemm_dw_slab_bytes((const CaseGemmDesc*)desc) : (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: null descriptor");
     default: return (int64_t)case_set_error(CASE_E_ARG, "case_workspace_bytes: unknown kind %d", (int)kind);
   }
 }

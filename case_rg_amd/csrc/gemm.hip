@@ -37,6 +37,8 @@ struct Args {
   int vec_a, vec_b;  // 16-byte global loads are legal for the operand
   int vec_c;         // 16-byte accesses are legal for C / aux / aux_out / bias_col
   float* rowsum;     // case_gemm_dw_bias: pre-zeroed f32 [M], receives sum_k op(A)[m, k] (the bias gradient of a weight-gradient GEMM)
+  float* slabs;      // case_gemm_dw_slabs: split s of a split-K call stores its partial tile into slabs + s * slab_stride (no atomics)
+  int64_t slab_stride;
 };
 
 // The kernel body is parameterised by the workgroup size (gemm_impl.inc): 256 threads = 4 waves x (64x64) per 128x128
@@ -102,6 +104,8 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
   a.nwg = (int)nwg;
   a.alpha = d->alpha;
   a.rowsum = nullptr;
+  a.slabs = nullptr;
+  a.slab_stride = 0;
   a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
   // 16-byte loads need the contiguous extent, every leading stride and the base to be 16-byte multiples
   auto aligned = [&](const void* p, int64_t ld, int64_t s1, int64_t s2, int64_t extent) {
@@ -161,7 +165,65 @@ extern "C" int case_gemm_dw_bias(const CaseGemmDesc* d, const void* A, const voi
     return case_set_error(CASE_E_UNSUPPORTED, "case_gemm_dw_bias: needs the 256x256 tiling (see case_gemm_tile_for), a k-major A, "
                                               "the bare ATOMIC epilogue and f32 output");
   a.rowsum = d_bias;
-  return gemm_t8w::launch<float, true>(a, d->epilogue, d->a_kmajor, d->b_kmajor, device_cus(), (hipStream_t)stream);
+  return gemm_t8w::launch<float, 1>(a, d->epilogue, d->a_kmajor, d->b_kmajor, device_cus(), (hipStream_t)stream);
+}
+
+namespace {
+// C[m, n] (+)= sum over the splits, in split order, of the f32 slabs a case_gemm_dw_slabs GEMM left behind: every output element is summed
+// by one thread in one fixed order, so the weight gradient is bit-identical from run to run (the atomic form's is not).  One thread
+// per 4 consecutive outputs; the slab reads of a workgroup are 4 KiB runs.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, const int64_t quads,
+                                                            const int splits, const int64_t stride, const int accumulate) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + q;
+  const int64_t sq = stride / 4;
+  f32x4 acc = accumulate ? reinterpret_cast<const f32x4*>(C)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (int64_t)(s + u) * sq);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; s < splits; ++s) acc += __builtin_nontemporal_load(src + (int64_t)s * sq);
+  reinterpret_cast<f32x4*>(C)[q] = acc;
+}
+}  // namespace
+
+extern "C" int64_t case_gemm_dw_slab_bytes(const CaseGemmDesc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  const int kt = (int)((d->K + 63) / 64);
+  int split = d->split_k < 1 ? 1 : d->split_k;
+  split = split > kt ? kt : split;
+  const int per = (kt + split - 1) / split;
+  split = (kt + per - 1) / per;
+  return split < 2 ? 0 : (int64_t)split * d->M * d->N * 4;
+}
+
+extern "C" int case_gemm_dw_slabs(const CaseGemmDesc* d, const void* A, const void* B, void* C, float* d_bias, void* slabs,
+                                  int64_t slab_bytes, case_stream_t stream) {
+  Args a;
+  int tile = 0;
+  const int rc = prepare(d, A, B, C, nullptr, nullptr, nullptr, nullptr, a, &tile);
+  if (rc) return rc;
+  if (!(tile == 256 && d->epilogue == CASE_EPI_ATOMIC && d->out_dtype == CASE_F32 && d->ldc == d->N && a.split_k > 1 && (!d_bias || d->a_kmajor)))
+    return case_set_error(CASE_E_UNSUPPORTED, "case_gemm_dw_slabs: needs the 256x256 tiling (see case_gemm_tile_for), split_k > 1, the bare ATOMIC "
+                                              "epilogue, f32 output with ldc == N (and a k-major A for d_bias)");
+  CASE_REQUIRE(slabs && (uintptr_t)slabs % 16 == 0 && slab_bytes >= (int64_t)a.split_k * d->M * d->N * 4,
+               "case_gemm_dw_slabs: workspace of %lld bytes, %lld needed (case_gemm_dw_slab_bytes)", (long long)slab_bytes,
+               (long long)a.split_k * d->M * d->N * 4);
+  a.rowsum = d_bias;
+  a.slabs = reinterpret_cast<float*>(slabs);
+  a.slab_stride = d->M * d->N;
+  hipStream_t s = (hipStream_t)stream;
+  const int rg = gemm_t8w::launch<float, 2>(a, d->epilogue, d->a_kmajor, d->b_kmajor, device_cus(), s);
+  if (rg) return rg;
+  const int64_t quads = d->M * d->N / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.slabs, reinterpret_cast<float*>(C), quads,
+                     a.split_k, a.slab_stride, 1);
+  return case_check_launch("case_gemm_dw_slabs");
 }
 
 extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
@@ -174,9 +236,9 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
   hipStream_t s = (hipStream_t)stream;
   if (tile == 256) {
     const int cus = case_persistent_cus();
-    if (d->out_dtype == CASE_BF16) return gemm_t8w::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-    if (epi & CASE_EPI_ATOMIC) return gemm_t8w::launch<float, true>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
-    return gemm_t8w::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    if (d->out_dtype == CASE_BF16) return gemm_t8w::launch<bf16_t, 0>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    if (epi & CASE_EPI_ATOMIC) return gemm_t8w::launch<float, 1>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
+    return gemm_t8w::launch<float, 0>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
   }
   if (tile == 64) {
     if (d->out_dtype == CASE_BF16) return gemm_sm::launch<bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);

@@ -221,12 +221,34 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
         if not (a_kmajor and epilogue == A.EPI_ATOMIC and lda == M and batch1 * batch2 == 1 and a_off == 0):
             raise ValueError("rowsum_out needs an unbatched k-major contiguous A and the bare ATOMIC epilogue")
         if FUSE_BIAS_GRAD and a.dtype == torch.bfloat16 and A.lib.case_gemm_tile_for(d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), None, None, None) == 256:
-            A.call("case_gemm_dw_bias", d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), _ptr(rowsum_out), _stream())
+            if not _dw_slabs(d, a, b, b_off, c, c_off, rowsum_out):
+                A.call("case_gemm_dw_bias", d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), _ptr(rowsum_out), _stream())
             return c
         A.call("case_colsum", _ptr(a), _ptr(rowsum_out), K, M, _code(a), _stream())
+    elif (epilogue == A.EPI_ATOMIC and split_k >= DW_SLAB_MIN_SPLIT and a.dtype == torch.bfloat16 and batch1 * batch2 == 1 and a_off == 0
+          and A.lib.case_gemm_tile_for(d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), None, None, None) == 256 and _dw_slabs(d, a, b, b_off, c, c_off, None)):
+        return c
     A.call("case_gemm", d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(bias_row), _ptr(aux),
            _ptr(aux_out), _stream())
     return c
+
+
+# split-K weight gradients with at least this many splits (small outputs, long reductions: the 512 x 512 gradients over 122,880
+# tokens run 64) go through per-split slabs + an ordered reduction instead of f32 atomics (case_gemm_dw_slabs); 0 switches it off
+DW_SLAB_MIN_SPLIT = int(os.environ.get("CASE_DW_SLAB_MIN_SPLIT", "8"))
+DW_SLAB_MAX_BYTES = 256 << 20
+
+
+def _dw_slabs(d, a, b, b_off, c, c_off, rowsum_out):
+    """Run the weight-gradient GEMM described by ``d`` through case_gemm_dw_slabs when it qualifies; False = caller takes the atomic path."""
+    if DW_SLAB_MIN_SPLIT <= 0 or d.split_k < DW_SLAB_MIN_SPLIT or d.ldc != d.N:
+        return False
+    need = A.lib.case_gemm_dw_slab_bytes(d)
+    if need <= 0 or need > DW_SLAB_MAX_BYTES:
+        return False
+    ws = torch.empty(need, dtype=torch.uint8, device=c.device)  # stream-ordered: the caching allocator hands it on after the reduce
+    A.call("case_gemm_dw_slabs", d, _ptr(a), _ptr(b, b_off), _ptr(c, c_off), _ptr(rowsum_out), _ptr(ws), need, _stream())
+    return True
 
 
 def _split_for(out_rows, out_cols, k_len, elem_bytes):

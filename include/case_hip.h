@@ -55,7 +55,8 @@ enum {
   CASE_FEAT_ATTN_DECODE = 1u << 4,     /* case_attention_decode */
   CASE_FEAT_OPTIM = 1u << 5,           /* K15 case_optim_* */
   CASE_FEAT_ATTN_RESIDENT = 1u << 6,   /* K18 / K19 behind case_attention_fwd / _bwd */
-  CASE_FEAT_RESERVED_CUS = 1u << 7     /* case_set_reserved_cus */
+  CASE_FEAT_RESERVED_CUS = 1u << 7,    /* case_set_reserved_cus */
+  CASE_FEAT_GEMM_DW_SLABS = 1u << 8    /* case_gemm_dw_slabs: atomics-free, run-to-run deterministic split-K weight gradients */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -72,8 +73,9 @@ int case_get_reserved_cus(void);
  *   CASE_WS_ATTENTION_BWD      desc = CaseAttnDesc*                   (the `delta` argument of case_attention_bwd)
  *   CASE_WS_OPTIM_SUMSQ        arg = nchunks                          (the `partials` argument of case_optim_sumsq)
  *   CASE_WS_ENCODER_CHAIN_PACK                                        (the packed weights of case_encoder_chain_pack)
+ *   CASE_WS_GEMM_DW_SLABS      desc = CaseGemmDesc*                   (the `slabs` argument of case_gemm_dw_slabs; 0 = no split)
  * negative = CASE_E_ARG. */
-typedef enum { CASE_WS_ATTENTION_SPLITKV = 1, CASE_WS_ATTENTION_BWD = 2, CASE_WS_OPTIM_SUMSQ = 3, CASE_WS_ENCODER_CHAIN_PACK = 4 } case_workspace_kind_t;
+typedef enum { CASE_WS_ATTENTION_SPLITKV = 1, CASE_WS_ATTENTION_BWD = 2, CASE_WS_OPTIM_SUMSQ = 3, CASE_WS_ENCODER_CHAIN_PACK = 4, CASE_WS_GEMM_DW_SLABS = 5 } case_workspace_kind_t;
 int64_t case_workspace_bytes(int32_t kind, const void* desc, int64_t arg);
 
 /* ---------------------------------------------------------------------------------------------
@@ -132,6 +134,16 @@ int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, cons
  * and d_bias[m] += sum_k op(A)[m, k] (f32 [M], pre-zeroed, atomics).  Only for calls the 256x256 tiling takes with a k-major A
  * (case_gemm_tile_for(...) == 256, d->a_kmajor): CASE_E_UNSUPPORTED otherwise, and the caller runs case_gemm + case_colsum. */
 int case_gemm_dw_bias(const CaseGemmDesc* d, const void* A, const void* B, void* C, float* d_bias, case_stream_t stream);
+/* The same weight-gradient GEMM without atomics on C: every K split stores its partial [M, N] f32 tile into its own slab of the
+ * caller's workspace (16-byte aligned, >= case_gemm_dw_slab_bytes(d) bytes, free again when the stream has passed the call) and a
+ * second launch adds the slabs to C in split order -- C[M, N] += op(A) op(B), bit-identical from run to run.  For the small,
+ * deeply split outputs (a 512 x 512 weight gradient over 122,880 tokens = 64 splits) it is also ~2x faster: 64 MiB of f32 red ops
+ * retire at ~1.3 TB/s, plain stores + one read at HBM rate.  d_bias may be NULL; otherwise as in case_gemm_dw_bias (atomics, [M]).
+ * Needs the 256x256 tiling, split_k > 1 after clamping, ldc == N; CASE_E_UNSUPPORTED otherwise.  case_gemm_dw_slab_bytes returns
+ * 0 when the clamped split is 1. */
+int case_gemm_dw_slabs(const CaseGemmDesc* d, const void* A, const void* B, void* C, float* d_bias, void* slabs, int64_t slab_bytes,
+                       case_stream_t stream);
+int64_t case_gemm_dw_slab_bytes(const CaseGemmDesc* d);
 
 int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const void* B, const void* C, const float* bias_col,
                        const void* aux, const void* aux_out);

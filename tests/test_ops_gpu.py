@@ -3,6 +3,7 @@ against a plain PyTorch fp32 reference of the same op, forward and gradients.
 
 Tolerances: f32 mode 1e-3 relative to the tensor scale (north-star bar; the exact-f32 MFMA path is usually
 ~1e-6); bf16 mode is reported against its own bar (3e-2 of the tensor scale, bf16 has 8 mantissa bits)."""
+import ctypes
 import math
 
 import pytest
@@ -762,6 +763,54 @@ def test_weight_gradient_gemm_also_sums_the_bias_gradient():
         _close(db, g.float().sum(0), 2e-3, "bias gradient N=%d (fused on the 256 tiling: %s)" % (N, N % 256 == 0))
     with pytest.raises(ValueError):
         ops.gemm(g, x, dw, 320, 256, 576, 320, 256, 256, b_kmajor=True, epilogue=A.EPI_ATOMIC, rowsum_out=db)
+
+
+def test_weight_gradient_through_split_slabs_is_exact_and_repeatable():
+    """case_gemm_dw_slabs: the deeply split weight gradients (ops.gemm sends split_k >= DW_SLAB_MIN_SPLIT here) store one f32 slab per
+    split and sum them in a fixed order -- same value as the atomic form to f32 rounding, bit-identical from launch to launch, C is
+    accumulated into (+=), and the fused bias gradient still arrives."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    assert A.lib.case_abi_features() & A.FEAT_GEMM_DW_SLABS
+    dt = torch.bfloat16
+    for (Mtok, N, K, split, bias) in ((64 * 64, 512, 512, 16, True), (64 * 96, 256, 768, 12, False), (64 * 27, 512, 256, 9, True)):
+        g, x = _rand(Mtok, N, dt=dt, seed=1), _rand(Mtok, K, dt=dt, seed=2, scale=Mtok ** -0.5)
+        ref = g.float().t() @ x.float()
+        d = A.GemmDesc()
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.split_k = N, K, Mtok, N, K, K, split
+        assert A.lib.case_gemm_dw_slab_bytes(d) == split * N * K * 4 == A.lib.case_workspace_bytes(A.WS_GEMM_DW_SLABS, ctypes.addressof(d), 0)
+        outs = []
+        for rep in range(3):
+            dw = torch.full((N, K), 0.5 if rep == 2 else 0.0, device="cuda", dtype=torch.float32)
+            db = torch.zeros(N, device="cuda", dtype=torch.float32) if bias else None
+            trace = ops.TILE_TRACE = []
+            ops.GEMM_TILE = 256  # (the cost model would give test-sized problems to the 128 tiling)
+            try:
+                ops.gemm(g, x, dw, N, K, Mtok, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC, rowsum_out=db)
+            finally:
+                ops.GEMM_TILE, ops.TILE_TRACE = 0, None
+            assert trace[0] == 256
+            torch.cuda.synchronize()
+            outs.append(dw)
+            if bias:
+                _close(db, g.float().sum(0), 2e-3, "bias gradient beside the slabs N=%d" % N)
+        _close(outs[0], ref, 2e-3, "slab dW %dx%d split %d" % (N, K, split))
+        assert torch.equal(outs[0], outs[1]), "slab weight gradient differs between two launches"
+        _close(outs[2], ref + 0.5, 2e-3, "slab dW accumulates into C")
+    # the entry point refuses what it cannot run, and a short workspace
+    d = A.GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.split_k = 512, 512, 4096, 512, 512, 512, 16
+    d.batch1 = d.batch2 = 1
+    d.a_kmajor = d.b_kmajor = 1
+    d.in_dtype, d.out_dtype, d.epilogue, d.alpha, d.tile = A.BF16, A.F32, A.EPI_ATOMIC, 1.0, 256
+    g, x = _rand(4096, 512, dt=dt, seed=1), _rand(4096, 512, dt=dt, seed=2)
+    dw = torch.zeros(512, 512, device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="workspace"):
+        A.call("case_gemm_dw_slabs", d, g.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), 0)
+    d.split_k = 1
+    with pytest.raises(RuntimeError, match="split_k"):
+        A.call("case_gemm_dw_slabs", d, g.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), 0)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
