@@ -295,16 +295,49 @@ def _split_for(out_rows, out_cols, k_len, elem_bytes):
     return best
 
 
+class _ZeroArena:
+    """Zero-initialised f32 memory for the gradients of one training step, handed out in slices of ONE fill: the backward pass asked
+    for ~330 separately zeroed buffers per step (weight / bias gradients that are accumulated with atomics, LayerNorm and embedding
+    gradients), each a 4-microsecond fill launch on a GPU-bound step.  The arena of a step is sized by what the previous step took
+    (steps are told apart by PARAM_EPOCH, which the optimizer bumps); the first step, and anything beyond the estimate, falls back to
+    one allocation per request.  Gradients are views of the arena: it is freed when the last of them dies (zero_grad, or GradSync's
+    switch to its bucket views)."""
+    ENABLED = os.environ.get("CASE_ZERO_ARENA", "1") != "0"
+    ALIGN = 64  # floats: every slice starts on a 256-byte boundary
+
+    def __init__(self):
+        self.epoch, self.buf, self.pos, self.served, self.want, self.device = -1, None, 0, 0, 0, None
+
+    def take(self, n, device):
+        if not self.ENABLED or not torch.device(device).type == "cuda":
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        if self.epoch != PARAM_EPOCH or self.device != device:
+            self.want = self.served if self.device == device else 0
+            self.epoch, self.buf, self.pos, self.served, self.device = PARAM_EPOCH, None, 0, 0, device
+        step = (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.served += step
+        if self.buf is None or self.pos + step > self.buf.numel():
+            size = self.want - (self.served - step) if self.buf is None else 0  # the rest of the estimate, once
+            if size < step:
+                return torch.zeros(n, dtype=torch.float32, device=device)
+            self.buf, self.pos = torch.zeros(size, dtype=torch.float32, device=device), 0
+        out = self.buf[self.pos:self.pos + n]
+        self.pos += step
+        return out
+
+
+_ZEROS = _ZeroArena()
+
+
 def _zeros_like_shapes(device, *shapes):
-    """Zero-initialised f32 tensors for atomically accumulated gradients, carved out of ONE allocation (one fill kernel for a
-    weight gradient and its bias gradient instead of two: the step launched 660 four-microsecond fills).  Each tensor starts
-    on a 16-byte boundary."""
+    """Zero-initialised f32 tensors for atomically accumulated gradients, carved out of ONE slice of the step's zero arena (one fill
+    kernel per step instead of one per gradient).  Each tensor starts on a 16-byte boundary."""
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     offs, total = [], 0
     for n in sizes:
         offs.append(total)
         total += (n + 3) // 4 * 4
-    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    flat = _ZEROS.take(total, device)
     return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
@@ -312,14 +345,14 @@ def _weight_grad(g2, x2, N, K, out=None, bias_out=None):
     """dW[N, K] = g2[M, N]^T x2[M, K]  (both operands k-major, f32 atomics across K splits); ``out`` is pre-zeroed.
     ``bias_out`` (pre-zeroed f32 [N]) also receives the bias gradient, the column sums of g2 (see ``gemm(rowsum_out=)``)."""
     M = g2.shape[0]
-    dw = out if out is not None else torch.zeros(N, K, dtype=torch.float32, device=g2.device)
+    dw = out if out is not None else _zeros_like_shapes(g2.device, (N, K))[0]
     split = _split_for(N, K, M, g2.element_size())
     gemm(g2, x2, dw, N, K, M, N, K, K, a_kmajor=True, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC, rowsum_out=bias_out)
     return dw
 
 
 def _colsum(g2, out=None):
-    out = out if out is not None else torch.zeros(g2.shape[1], dtype=torch.float32, device=g2.device)
+    out = out if out is not None else _zeros_like_shapes(g2.device, (g2.shape[1],))[0]
     A.call("case_colsum", _ptr(g2), _ptr(out), g2.shape[0], g2.shape[1], _code(g2), _stream())
     return out
 
@@ -342,7 +375,7 @@ def _input_grad(g, wc, M, K, N):
     if g.dtype == torch.bfloat16 and N >= 4096 and tiles < 256:
         split = _split_for(M, K, N, 2)
         if split > 1:
-            acc = torch.zeros(M, K, dtype=torch.float32, device=g.device)
+            acc = _zeros_like_shapes(g.device, (M, K))[0]
             gemm(g, wc, acc, M, K, N, N, K, K, b_kmajor=True, split_k=split, epilogue=A.EPI_ATOMIC)
             return cast(acc, g.dtype)
     dx = torch.empty(M, K, dtype=g.dtype, device=g.device)
@@ -438,8 +471,8 @@ class RowDotFn(Function):
         R, C = x2.shape
         g = g.reshape(-1).float().contiguous()
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros(C, dtype=torch.float32, device=x2.device)
-        db = torch.zeros(1, dtype=torch.float32, device=x2.device) if has_b else None
+        dw, db = _zeros_like_shapes(x2.device, (C,), (1,))
+        db = db if has_b else None
         A.call("case_rowdot_bwd", _ptr(g), _ptr(x2), _ptr(wv), _ptr(dx), _ptr(dw), _ptr(db), R, C, _code(x2), _stream())
         return (None if dx is None else dx.view(xshape)), dw.view(wshape), db
 
@@ -1033,7 +1066,7 @@ class EmbedPosFn(Function):
         (ids_c,) = ctx.saved_tensors
         V, H, scale, drop = ctx.meta
         d_out = d_out if d_out.is_contiguous() else d_out.contiguous()
-        d_table = torch.zeros(V, H, dtype=torch.float32, device=d_out.device)
+        d_table = _zeros_like_shapes(d_out.device, (V, H))[0]
         A.call("case_embed_pos_bwd", _ptr(ids_c), _ptr(d_out), _ptr(d_table), ids_c.numel(), H, V, scale, drop[0], drop[1],
                drop[2], _code(d_out), _stream())
         return None, d_table, None, None, None, None
@@ -1165,7 +1198,7 @@ class ScaleColsFn(Function):
         C = x.shape[-1]
         g = g if g.is_contiguous() else g.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.zeros(C, dtype=torch.float32, device=x.device)
+        dw = _zeros_like_shapes(x.device, (C,))[0]
         A.call("case_scale_cols_bwd", _ptr(g), _ptr(x), _ptr(wc), _ptr(dx), _ptr(dw), x.numel() // C, C, _code(x), _stream())
         return dx, dw
 
@@ -1303,7 +1336,7 @@ class AdditiveScoresFn(Function):
         ds = ds.float().contiguous()
         d_wq = torch.empty_like(wq)
         d_uh = torch.empty(B, S, H, dtype=torch.float32, device=wq.device)
-        d_v = torch.zeros(H, dtype=torch.float32, device=wq.device)
+        d_v = _zeros_like_shapes(wq.device, (H,))[0]
         A.call("case_additive_scores_bwd", _ptr(ds), _ptr(wq), _ptr(uh), _ptr(vv), _ptr(d_wq), _ptr(d_uh), _ptr(d_v), B, T, S, H,
                _code(uh), _stream())
         return d_wq, cast(d_uh, uh.dtype), d_v

@@ -765,6 +765,35 @@ def test_weight_gradient_gemm_also_sums_the_bias_gradient():
         ops.gemm(g, x, dw, 320, 256, 576, 320, 256, 256, b_kmajor=True, epilogue=A.EPI_ATOMIC, rowsum_out=db)
 
 
+def test_zero_arena_serves_one_fill_per_step_with_disjoint_zeroed_slices():
+    """ops._ZeroArena: from the second step on (steps = optimizer updates = ops.PARAM_EPOCH) every zero-initialised gradient buffer of
+    the backward pass is a slice of ONE zero-filled allocation sized by the previous step; slices are zero when handed out, disjoint,
+    256-byte aligned, and requests beyond the estimate fall back to their own allocation."""
+    ops = _ops()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    shapes = [(512, 512), (512,), (7,), (1536, 512), (1,)]
+    ops._ZEROS.__init__()  # forget what earlier tests of this process took
+    storages = []
+    for step in range(3):
+        ops.invalidate_param_cache()  # what the optimizer does after writing the parameters
+        got = []
+        for rep in range(2):
+            got += ops._zeros_like_shapes(dev, *shapes)
+        extra = ops._zeros_like_shapes(dev, (300, 300))[0] if step == 2 else None  # beyond what step 1 took
+        for t, sh in zip(got, shapes * 2):
+            assert t.shape == torch.Size(sh) and t.dtype == torch.float32 and not t.any().item()
+        for i, t in enumerate(got):
+            t.fill_(float(i + 1))
+        for i, t in enumerate(got):
+            assert (t == float(i + 1)).all().item(), "slices overlap"
+        storages.append({t.untyped_storage().data_ptr() for t in got})
+        if extra is not None:
+            assert not extra.any().item() and extra.untyped_storage().data_ptr() not in storages[-1]
+        del got
+    assert len(storages[0]) == 2, "first step: no estimate yet, one allocation per request"
+    assert len(storages[1]) == 1 and len(storages[2]) == 1, "later steps: one arena"
+
+
 def test_weight_gradient_through_split_slabs_is_exact_and_repeatable():
     """case_gemm_dw_slabs: the deeply split weight gradients (ops.gemm sends split_k >= DW_SLAB_MIN_SPLIT here) store one f32 slab per
     split and sum them in a fixed order -- same value as the atomic form to f32 rounding, bit-identical from launch to launch, C is
