@@ -18,7 +18,7 @@ import sys
 
 def family(name):
     """C++ kernel name -> the family key bench.py prints."""
-    m = re.search(r"gemm8w_kernel<(unsigned short|float), (true|false), (true|false), (true|false)>", name)
+    m = re.search(r"gemm8w_kernel<(unsigned short|float), (true|false), (true|false), (true|false|\d)>", name)  # last: 0 plain, 1 atomics, 2 slabs
     if m:
         return "gemm8w_kernel<bf16,%s,%s,%s>" % ("bf16" if m.group(1) == "unsigned short" else "f32",
                                                     "Ak" if m.group(2) == "true" else "A", "Bk" if m.group(3) == "true" else "B")
@@ -35,6 +35,9 @@ def family(name):
     if m:
         return "chain_kernel<%s>" % {"0": "full", "1": "tail", "2": "head"}.get(m.group(1), m.group(1))
     m = re.search(r"(scores_kernel<(?:true|false)>|rc_gemm_kernel<(?:true|false)>)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"(fa64::fwd_kernel<(?:true|false)>|fa64::bwd::bwd_kernel<(?:true|false)>|fa64::bwd::stat_kernel|splitk_reduce_kernel)", name)
     if m:
         return m.group(1)
     m = re.search(r"(attn_decode\w*|fa_fwd\w*_kernel|fa_bwd\w*_kernel)", name)
