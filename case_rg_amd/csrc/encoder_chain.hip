@@ -30,6 +30,8 @@
 //     epilogue each lane reads the 8 bytes of s2 it is about to overwrite with gelu(.) and seeds its FFN2 accumulators with them;
 //   * LayerNorm statistics: per-lane partial sums over the f32 accumulators, two cross-lane adds, one 8 KiB exchange through LDS.
 // Variants: HEAD (layer 0: x -> LN1 -> s, qkv), FULL (layer i -> i + 1), TAIL (last layer: o is the encoder output).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace enc_chain {
@@ -142,8 +144,10 @@ __device__ uint64_t g_stamps[256 * 32];
 #define STAMP_WAVE 0
 #endif
 
-template <int VARIANT>
+// HALF: 64-token tiles (token blocks 0 .. 3 only) -- the launch that finishes a partial last round on ALL workgroups, see launch()
+template <int VARIANT, bool HALF>
 __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
+  constexpr int TOKT = HALF ? TOK / 2 : TOK, NTB = TOKT / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lt = l & 15, lg = l >> 4;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 
   constexpr int ST0 = VARIANT == VAR_HEAD ? 3 : 0, ST1 = VARIANT == VAR_TAIL ? 3 : 6;  // stages: 0 out-proj, 1 FFN1, 2 FFN2, 3..5 Q / K / V
   constexpr int NSTEP = (ST1 - ST0) * KSTEPS;  // K steps per tile of this wave's weight stream
-  const int ntiles = (int)((g.M + TOK - 1) / TOK);
+  const int ntiles = (int)((g.M + TOKT - 1) / TOKT);
   const int n0 = 64 * wave;  // the wave's feature columns inside every stage's 512-wide output
 
   // the wave's weight stream: step s (0 .. NSTEP-1, wrapping for the next tile) = 4 fragments at s * STEP_BYTES
@@ -196,16 +200,16 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #define EC_XREAD(KS)                                                                                                                 \
     {                                                                                                                                \
       const char* pn = smem + xl + (((KS) ^ xh) << 6);                                                                               \
-      _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);                   \
+      _Pragma("unroll") for (int tb = 0; tb < NTB; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);                   \
     }
 #else
-#define EC_XREAD(KS) { if ((KS) == 0) { const char* pn = smem + xl; _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384); } }
+#define EC_XREAD(KS) { if ((KS) == 0) { const char* pn = smem + xl; _Pragma("unroll") for (int tb = 0; tb < NTB; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384); } }
 #endif
 #define EC_STEP(W, KS)                                                                                                              \
   {                                                                                                                                  \
-    bf16x8 xf[8];                                                                                                                    \
+    bf16x8 xf[NTB];                                                                                                                    \
     EC_XREAD(KS)                                                                                                                     \
-    _Pragma("unroll") for (int tb = 0; tb < 8; ++tb) {                                                                               \
+    _Pragma("unroll") for (int tb = 0; tb < NTB; ++tb) {                                                                               \
       _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                               \
         acc[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&W[nb]), xf[tb], acc[tb][nb], 0, 0, 0); \
     }                                                                                                                                \
@@ -242,14 +246,14 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #endif
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = (int64_t)tile * TOK;
-    const int rows = (int)(g.M - row0 < TOK ? g.M - row0 : TOK);
+    const int64_t row0 = (int64_t)tile * TOKT;
+    const int rows = (int)(g.M - row0 < TOKT ? g.M - row0 : TOKT);
     const uint32_t tile_bytes_e = (uint32_t)rows * E * 2;
     const __amdgpu_buffer_rsrc_t rso = as_rsrc(g.s_out + row0 * E, tile_bytes_e);
     const __amdgpu_buffer_rsrc_t rqkv = as_rsrc(g.qkv_out ? g.qkv_out + row0 * (3 * E) : nullptr, g.qkv_out ? (uint32_t)rows * 3 * E * 2 : 0);
 
     EC_STAMP(0)
-    f32x4 acc[8][4];
+    f32x4 acc[NTB][4];
     // ---- stage 0 accumulators: bo + s (requested now, in flight under the tile DMA) -----------------------------------------
     // (row layout: 32 contiguous bytes per lane; two halves of four token blocks keep the registers in flight at 32)
     u32x4 rr[4][2];
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
     {
       const i32x4 rs = make_rsrc(g.ctx + row0 * E, tile_bytes_e);
 #pragma unroll 4
-      for (int i = 0; i < TOK / NWAVE; ++i) {
-        const int r = wave * (TOK / NWAVE) + i;
+      for (int i = 0; i < TOKT / NWAVE; ++i) {
+        const int r = wave * (TOKT / NWAVE) + i;
         dma16(rs, (unsigned)(r * 1024 + ((l ^ (r & 15)) << 4)), lds0 + r * 1024);
       }
     }
@@ -276,13 +280,13 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(g.bo + n0 + 16 * nb + 4 * lg);  // first tile: LDS copy not yet visible
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < NTB / 4; ++half) {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
           const int tb = half * 4 + t4;
           // row layout -> accumulator layout: the same 4 x 4 lane-row transpose
           uint32_t lo[4] = {rr[t4][0][0], rr[t4][0][2], rr[t4][1][0], rr[t4][1][2]}, hi[4] = {rr[t4][0][1], rr[t4][0][3], rr[t4][1][1], rr[t4][1][3]};
-          if (half == 0) {  // the second half's rows are requested as the first half's registers come free
+          if (half == 0 && !HALF) {  // the second half's rows are requested as the first half's registers come free
             rr[t4][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row, (tb + 4) * 16 * E * 2, 0);
             rr[t4][1] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row, (tb + 4) * 16 * E * 2 + 16, 0);
           }
@@ -312,12 +316,12 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { gam[e + i] = a[i]; bet[e + i] = b[i]; }
       }
-      for (int i = 0; i < TOK / NWAVE; i += 2) {
+      for (int i = 0; i < TOKT / NWAVE; i += 2) {
         float x[2][8], s1[2], s2[2];
         u32x4* p[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int r = wave * (TOK / NWAVE) + i + u;
+          const int r = wave * (TOKT / NWAVE) + i + u;
           p[u] = reinterpret_cast<u32x4*>(smem + x_off(r, l));
           const u32x4 w = *p[u];
           s1[u] = 0.f;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
         for (int o = 32; o > 0; o >>= 1) { s2[0] += __shfl_xor(s2[0], o, 64); s2[1] += __shfl_xor(s2[1], o, 64); }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int r = wave * (TOK / NWAVE) + i + u;
+          const int r = wave * (TOKT / NWAVE) + i + u;
           const float rstd = rsqrtf(s2[u] * (1.f / E) + g.eps1n);
           u32x4 o;
 #pragma unroll
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
     for (int st = ST0; st < (ST1 < 3 ? ST1 : 3); ++st) {
       if (st == 1) {  // no residual in front of the GEMM: the bias is added in the epilogue
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb)
+        for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb) acc[tb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
           const f32x4 b2v = *reinterpret_cast<const f32x4*>(par + P_B2 + n0 + 16 * nb + 4 * lg);
           char* px = smem + wbase + (((2 * nb) ^ q) << 4);
 #pragma unroll
-          for (int tb = 0; tb < 8; ++tb) {
+          for (int tb = 0; tb < NTB; ++tb) {
             u32x2* p = reinterpret_cast<u32x2*>(px + tb * 16384);
             const u32x2 old = *p;
             u32x2 w;
@@ -402,10 +406,10 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
       }
       // st == 0 (y -> LN2 -> s2) or st == 2 (o -> LN1' -> s'; TAIL: o itself)
       const bool do_ln = !(VARIANT == VAR_TAIL && st == 2);
-      float mean[8], rstd[8];
+      float mean[NTB], rstd[NTB];
       if (do_ln) {
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
+        for (int tb = 0; tb < NTB; ++tb) {
           float a = 0.f, b = 0.f;
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
       if (do_ln) {
         const float eps = st == 0 ? g.eps2 : g.eps1n;
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
+        for (int tb = 0; tb < NTB; ++tb) {
           // lane group lg adds the partial sums of waves 2 lg and 2 lg + 1 (one 16-byte read), two cross-lane adds finish the row
           const f32x4 p = *reinterpret_cast<const f32x4*>(stats + ((tb * 16 + lt) * NWAVE + 2 * lg) * 2);
           float s1 = p[0] + p[2], s2 = p[1] + p[3];
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
         const float* bet = par + (st == 0 ? P_BE2 : P_BE1N);
         int q2 = xq2, rbase = xr;
         asm volatile("" : "+v"(q2), "+v"(rbase));
-        uint32_t pk[8][4][2];  // packed bf16 pairs: the accumulators die as they are packed (two registers for four)
+        uint32_t pk[NTB][4][2];  // packed bf16 pairs: the accumulators die as they are packed (two registers for four)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {  // pass 1, per feature block: gamma / beta of one block live at a time
           f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
             bt = *reinterpret_cast<const f32x4*>(bet + n0 + 16 * nb + 4 * lg);
           }
 #pragma unroll
-          for (int tb = 0; tb < 8; ++tb) {
+          for (int tb = 0; tb < NTB; ++tb) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = do_ln ? ((acc[tb][nb][e] - mean[tb]) * rstd[tb]) * gm[e] + bt[e] : acc[tb][nb][e];
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
         char* pa = smem + rbase + (q2 << 4);
         char* pb = smem + rbase + ((q2 ^ 1) << 4);
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {  // pass 2, per token block: lane-row transpose, write X (and the global copy)
+        for (int tb = 0; tb < NTB; ++tb) {  // pass 2, per token block: lane-row transpose, write X (and the global copy)
           uint32_t lo[4] = {pk[tb][0][0], pk[tb][1][0], pk[tb][2][0], pk[tb][3][0]}, hi[4] = {pk[tb][0][1], pk[tb][1][1], pk[tb][2][1], pk[tb][3][1]};
           u32x4 w0, w1;
           to_rows(lo, hi, w0, w1);
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
         }
     for (int st = (ST0 > 3 ? ST0 : 3); st < ST1; ++st) {  // Q / K / V: + bias, pack, lane-row transpose, store [M, 1536] as 16-byte vectors
 #pragma unroll
-      for (int tb = 0; tb < 8; ++tb)
+      for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[tb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       EC_KLOOP
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bias + 16 * nb);
 #pragma unroll
-      for (int tb = 0; tb < 8; ++tb) {
+      for (int tb = 0; tb < NTB; ++tb) {
         uint32_t lo[4], hi[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -522,19 +526,49 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #undef EC_REQUEST
 }
 
-template <int VARIANT>
-int launch(const Args& a, int cus, hipStream_t s) {
-  const int ntiles = (int)((a.M + TOK - 1) / TOK);
-  const dim3 grid(ntiles < cus ? ntiles : cus), block(NTHR);
+template <int VARIANT, bool HALF>
+int launch_one(const Args& a, int grid_max, hipStream_t s) {
+  constexpr int TOKT = HALF ? TOK / 2 : TOK;
+  const int ntiles = (int)((a.M + TOKT - 1) / TOKT);
+  const dim3 grid(ntiles < grid_max ? ntiles : grid_max), block(NTHR);
   static bool attr = false;  // (once per instantiation)
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<VARIANT, HALF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
         hipSuccess)
       return case_set_error(CASE_E_LAUNCH, "case_encoder_chain: cannot reserve %d bytes of LDS", LDS_BYTES);
     attr = true;
   }
-  hipLaunchKernelGGL((chain_kernel<VARIANT>), grid, block, LDS_BYTES, s, a);
+  hipLaunchKernelGGL((chain_kernel<VARIANT, HALF>), grid, block, LDS_BYTES, s, a);
   return case_check_launch("case_encoder_chain");
+}
+
+// One workgroup per CU walks 128-token tiles in rounds of the grid.  When the LAST round would occupy at most half of the workgroups
+// (1920 tiles on 256 workgroups: 7.5 rounds) the whole rounds run as one launch and the rest as a second launch of 64-token tiles on
+// twice as many workgroups: a half tile streams the same weights but has half the MFMA / epilogue / tile I-O work (~0.6 of a tile), and
+// nobody sits out an eighth round.  CASE_CHAIN_HALVES=0 switches the split off (A/B measurements).
+template <int VARIANT>
+int launch(const Args& a, int cus, hipStream_t s) {
+  static const bool split_ok = [] {
+    const char* e = getenv("CASE_CHAIN_HALVES");
+    return !(e && e[0] == '0');
+  }();
+  const int64_t ntiles = (a.M + TOK - 1) / TOK;
+  const int64_t whole = ntiles / cus * cus, rem = ntiles - whole;
+  if (!split_ok || rem == 0 || 2 * rem > cus) return launch_one<VARIANT, false>(a, cus, s);
+  if (whole > 0) {
+    Args f = a;
+    f.M = whole * TOK;
+    const int rc = launch_one<VARIANT, false>(f, cus, s);
+    if (rc) return rc;
+  }
+  Args h = a;
+  const int64_t r0 = whole * TOK;
+  h.M = a.M - r0;
+  h.ctx = a.ctx + r0 * E;
+  if (a.resid) h.resid = a.resid + r0 * E;
+  h.s_out = a.s_out + r0 * E;
+  if (a.qkv_out) h.qkv_out = a.qkv_out + r0 * 3 * E;
+  return launch_one<VARIANT, true>(h, cus, s);
 }
 
 }  // namespace enc_chain

@@ -26,7 +26,7 @@ def bf16_mode():
     case_rg_amd.set_compute_dtype(torch.float32)
 
 
-@pytest.mark.parametrize("N,L,layers", [(3, 384, 2), (5, 100, 3), (1, 40, 1), (7, 384, 6)])
+@pytest.mark.parametrize("N,L,layers", [(3, 384, 2), (5, 100, 3), (1, 40, 1), (7, 384, 6), (86, 384, 2)])  # the last: 258 tiles = one whole round of full tiles + half tiles
 def test_chain_matches_the_single_launch_path_and_the_oracle(bf16_mode, N, L, layers):
     import oracle
     from case_rg_amd import _abi, ops
