@@ -11,7 +11,7 @@ cnt = collections.Counter()
 with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
         name = re.sub(r"\(.*$", "", re.sub(r"void |\(anonymous namespace\)::", "", r["Kernel_Name"]))
-        if not any(k in name for k in ("gemm", "fa_", "Cijk", "chain_kernel", "attn_", "scores_kernel")):
+        if not any(k in name for k in ("gemm", "fa_", "fa64", "Cijk", "chain_kernel", "attn_", "scores_kernel")):
             continue
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
