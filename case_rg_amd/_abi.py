@@ -79,6 +79,7 @@ SIGNATURES = {
     "case_attention_product_supported": [C.POINTER(AttnProductDesc)],
     "case_attention_product": [C.POINTER(AttnProductDesc), ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],
+    "case_add_n": [C.POINTER(ptr), i32, ptr, i64, i32, ptr],
     "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],
     "case_mask_rows": [ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_colsum": [ptr, ptr, i64, i64, i32, ptr],

@@ -38,20 +38,24 @@ class Interaction(nn.Module):
         w = self.dual_att_linear.weight
         w1, w2, w3 = w[:, :H], w[:, H:2 * H], w[0, 2 * H:]
         f32 = torch.float32
-        cq = ops.linear(Eq, w1, out_dtype=f32).reshape(n, Lq)  # w1 . Eq[j]
-        ap = ops.linear(Ep, w2, out_dtype=f32).reshape(n, Lp)  # w2 . Ep[i]
-        Epw = ops.scale_cols(Ep, w3)
-        U = ops.bmm(Epw, Eq, bias_row=ap, out_dtype=f32) + cq.unsqueeze(1)   # [n, Lp, Lq]
-        Ut = ops.bmm(Eq, Epw, bias_row=cq, out_dtype=f32) + ap.unsqueeze(1)  # [n, Lq, Lp]
+        # every tensor below feeds 2 - 5 products: ops.fanout hands each consumer its own alias, so that the backward pass sums the
+        # gradients of one tensor in ONE kernel (autograd would add them pairwise: 12 elementwise launches per call on [n, L, H] tensors)
+        Ep_w2, Ep_w3, Ep_b1, Ep_g = ops.fanout(Ep, 4)
+        Eq_w1, Eq_u, Eq_ut, Eq_a1, Eq_g = ops.fanout(Eq, 5)
+        cq = ops.linear(Eq_w1, w1, out_dtype=f32).reshape(n, Lq)  # w1 . Eq[j]
+        ap = ops.linear(Ep_w2, w2, out_dtype=f32).reshape(n, Lp)  # w2 . Ep[i]
+        Epw_u, Epw_ut = ops.fanout(ops.scale_cols(Ep_w3, w3), 2)
+        U = ops.bmm(Epw_u, Eq_u, bias_row=ap, out_dtype=f32) + cq.unsqueeze(1)     # [n, Lp, Lq]
+        Ut = ops.bmm(Eq_ut, Epw_ut, bias_row=cq, out_dtype=f32) + ap.unsqueeze(1)  # [n, Lq, Lp]
         dt = Ep.dtype
-        A = ops.masked_softmax(U, qv, pv, outer=n, out_dtype=dt)    # softmax over the query axis
-        Bt = ops.masked_softmax(Ut, pv, qv, outer=n, out_dtype=dt)  # softmax over the passage axis, transposed
-        A1 = ops.bmm(A, Eq, b_is_kn=True)    # [n, Lp, H]
-        B1 = ops.bmm(Bt, Ep, b_is_kn=True)   # [n, Lq, H]
-        A2 = ops.bmm(A, B1, b_is_kn=True)
-        B2 = ops.bmm(Bt, A1, b_is_kn=True)
-        G_q_p = ops.concat5(Ep, A1, A2, pv).reshape(B, P, Lp, 5 * H)
-        G_p_q = ops.concat5(Eq, B1, B2, qv).reshape(B, P, Lq, 5 * H)
+        A_1, A_2 = ops.fanout(ops.masked_softmax(U, qv, pv, outer=n, out_dtype=dt), 2)     # softmax over the query axis
+        Bt_1, Bt_2 = ops.fanout(ops.masked_softmax(Ut, pv, qv, outer=n, out_dtype=dt), 2)  # softmax over the passage axis, transposed
+        A1_b, A1_g = ops.fanout(ops.bmm(A_1, Eq_a1, b_is_kn=True), 2)    # [n, Lp, H]
+        B1_a, B1_g = ops.fanout(ops.bmm(Bt_1, Ep_b1, b_is_kn=True), 2)   # [n, Lq, H]
+        A2 = ops.bmm(A_2, B1_a, b_is_kn=True)
+        B2 = ops.bmm(Bt_2, A1_b, b_is_kn=True)
+        G_q_p = ops.concat5(Ep_g, A1_g, A2, pv).reshape(B, P, Lp, 5 * H)
+        G_p_q = ops.concat5(Eq_g, B1_g, B2, qv).reshape(B, P, Lq, 5 * H)
         if nq != P:
             G_p_q = ops.max_over_p(G_p_q)
         return G_p_q, G_q_p

@@ -112,8 +112,10 @@ class TransformerDecoder(nn.Module):
         self.norm = norm
 
     def forward_batch_first(self, x, memory, tgt_valid=None, memory_valid=None, causal=True, memory_kvs=None):
+        # one alias of the memory per layer (each layer projects it to K / V): its gradient is then summed in one pass (ops.fanout)
+        mems = ops.fanout(memory, len(self.layers)) if memory_kvs is None else (memory,) * len(self.layers)
         for i, layer in enumerate(self.layers):
-            x = layer.forward_batch_first(x, memory, tgt_valid, memory_valid, causal,
+            x = layer.forward_batch_first(x, mems[i], tgt_valid, memory_valid, causal,
                                           None if memory_kvs is None else memory_kvs[i])
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)

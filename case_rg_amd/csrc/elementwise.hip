@@ -92,6 +92,30 @@ __global__ void add_vec_kernel(const T* __restrict__ a, const T* __restrict__ b,
   }
 }
 
+// out = src[0] + ... + src[n - 1] (2 <= n <= 8), summed in f32 and rounded once: the gradient of a tensor with n consumers in one pass
+// (autograd's own accumulation is n - 1 binary adds: 3 (n - 1) tensor passes against n + 1 here)
+struct AddNArgs {
+  const void* src[8];
+  int n;
+};
+template <typename T>
+__global__ void add_n_vec_kernel(const AddNArgs a, T* __restrict__ o, int64_t nvec) {
+  constexpr int E = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc[E], y[E];
+    Vec16<T>::load(reinterpret_cast<const T*>(a.src[0]) + i * E, acc);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      if (j < a.n) {
+        Vec16<T>::load(reinterpret_cast<const T*>(a.src[j]) + i * E, y);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += y[e];
+      }
+    }
+    Vec16<T>::store(o + i * E, acc);
+  }
+}
+
 template <typename T>
 __global__ void dropout_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t nvec, float p, uint64_t seed,
                                    uint64_t offset) {
@@ -500,6 +524,19 @@ extern "C" int case_add(const void* a, const void* b, void* out, int64_t n, int3
   if (n % ev == 0 && al16(a) && al16(b) && al16(out))
     EW_DISPATCH("case_add", n / ev, add_vec_kernel, (const T*)a, (const T*)b, (T*)out, n / ev);
   EW_DISPATCH("case_add", n, add_kernel, (const T*)a, (const T*)b, (T*)out, n);
+}
+
+extern "C" int case_add_n(const void* const* srcs, int32_t count, void* out, int64_t n, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(srcs && out && n > 0 && count >= 2 && count <= 8, "case_add_n: bad argument (2 <= count <= 8)");
+  const int ev = dtype == CASE_BF16 ? 8 : 4;
+  CASE_REQUIRE(n % ev == 0 && al16(out), "case_add_n: element count must be a multiple of %d and the tensors 16-byte aligned", ev);
+  AddNArgs a = {};
+  a.n = count;
+  for (int j = 0; j < count; ++j) {
+    CASE_REQUIRE(srcs[j] && al16(srcs[j]), "case_add_n: null or misaligned source %d", j);
+    a.src[j] = srcs[j];
+  }
+  EW_DISPATCH("case_add_n", n / ev, add_n_vec_kernel, a, (T*)out, n / ev);
 }
 
 extern "C" int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,

@@ -1168,6 +1168,53 @@ def cast_to(x, dtype):
 # ----------------------------------------------------------------------------------------------
 # small elementwise ops
 # ----------------------------------------------------------------------------------------------
+FANOUT = os.environ.get("CASE_FANOUT", "1") != "0"  # A/B switch: "0" leaves the gradient sums to autograd's binary adds
+
+
+def add_n(tensors):
+    """Sum of 2 .. 8 same-shaped tensors in one pass (f32 accumulation, one rounding)."""
+    ts = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+    out = torch.empty_like(ts[0])
+    arr = (A.ptr * len(ts))(*[t.data_ptr() for t in ts])
+    A.call("case_add_n", arr, len(ts), _ptr(out), out.numel(), _code(out), _stream())
+    return out
+
+
+class FanOutFn(Function):
+    """n aliases of one tensor for n consumers: the backward pass receives the n gradients TOGETHER and sums them in one kernel
+    (case_add_n: n + 1 tensor passes) instead of the autograd engine's n - 1 binary adds (3 (n - 1) passes, each intermediate rounded to
+    bf16).  Used where a large activation feeds several products: the Interaction tensors (common/Interaction.py:32-63) and the
+    memory of a decoder stack (one K / V projection per layer, common/TransformerDecoder.py:76-89)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        dt = gs[0].dtype
+        ev = 8 if dt == torch.bfloat16 else 4
+        if (not gs[0].is_cuda or dt not in (torch.bfloat16, torch.float32) or gs[0].numel() % ev or len(gs) > 8
+                or any(g.dtype != dt or g.shape != gs[0].shape for g in gs)):
+            total = gs[0]
+            for g in gs[1:]:
+                total = total + g
+            return total, None
+        return add_n(gs), None
+
+
+def fanout(x, n):
+    """``n`` aliases of ``x`` whose gradients are summed in one pass (identity when gradients are off or the switch is)."""
+    if n < 2 or not FANOUT or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return FanOutFn.apply(x, n)
+
+
 class AddFn(Function):
     @staticmethod
     def forward(ctx, a, b):

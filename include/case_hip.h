@@ -287,6 +287,10 @@ int case_attention_product(const CaseAttnProductDesc* d, const void* a, const vo
  * ------------------------------------------------------------------------------------------- */
 /* out = a + b  (residual adds: TransformerEncoder.py:68,75 etc.) */
 int case_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, case_stream_t stream);
+/* out = srcs[0] + ... + srcs[count - 1] (2 <= count <= 8; srcs is a HOST array of device pointers), summed in f32 and rounded once:
+ * the gradient of a tensor with several consumers in one pass (what autograd forms with count - 1 binary adds, e.g. the Interaction
+ * tensors of common/Interaction.py:32-63, each read by 2-5 products).  n a multiple of 16 bytes' worth of elements, 16-byte aligned. */
+int case_add_n(const void* const* srcs, int32_t count, void* out, int64_t n, int32_t dtype, case_stream_t stream);
 /* dropout with a counter RNG keyed by (seed, offset + element index); same call regenerates the mask in bwd */
 int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,
                  case_stream_t stream);

@@ -765,6 +765,39 @@ def test_weight_gradient_gemm_also_sums_the_bias_gradient():
         ops.gemm(g, x, dw, 320, 256, 576, 320, 256, 256, b_kmajor=True, epilogue=A.EPI_ATOMIC, rowsum_out=db)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fanout_sums_the_gradients_of_its_aliases_in_one_launch(dt):
+    """ops.fanout / case_add_n: n aliases for n consumers, ONE summing kernel in backward (f32 accumulation, one rounding); falls back to
+    plain adds for what the kernel does not take (odd sizes), is the identity without gradients."""
+    ops = _ops()
+    from case_rg_amd import _abi
+    for shape, n in (((6, 40, 64), 5), ((3, 7, 64), 2), ((5, 3), 3)):
+        x = _rand(*shape, dt=dt, seed=1).requires_grad_(True)
+        ws = [_rand(*shape, dt=dt, seed=10 + i) for i in range(n)]
+        calls = {}
+        raw = _abi.call
+
+        def counting(name, *a):
+            calls[name] = calls.get(name, 0) + 1
+            return raw(name, *a)
+
+        _abi.call = counting
+        try:
+            outs = ops.fanout(x, n)
+            assert len(outs) == n and all(o.data_ptr() == x.data_ptr() for o in outs)
+            loss = sum((o.float() * w.float()).sum() for o, w in zip(outs, ws))
+            loss.backward()
+        finally:
+            _abi.call = raw
+        want = sum(w.float() for w in ws)
+        _close(x.grad, want, 1e-6 if dt == torch.float32 else 8e-3, "fan-out gradient %s x %d" % (shape, n))
+        fits = x.numel() % (8 if dt == torch.bfloat16 else 4) == 0
+        assert calls.get("case_add_n", 0) == (1 if fits else 0)
+    with torch.no_grad():
+        y = _rand(4, 64, dt=dt, seed=2)
+        assert all(o is y for o in ops.fanout(y, 3))
+
+
 def test_zero_arena_serves_one_fill_per_step_with_disjoint_zeroed_slices():
     """ops._ZeroArena: from the second step on (steps = optimizer updates = ops.PARAM_EPOCH) every zero-initialised gradient buffer of
     the backward pass is a slice of ONE zero-filled allocation sized by the previous step; slices are zero when handed out, disjoint,
