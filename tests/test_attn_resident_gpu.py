@@ -154,3 +154,45 @@ def test_resident_backward_equals_unfused_path_with_dropout():
             assert err < 2e-2, (name, err)
     finally:
         config.set_dropout(False)
+
+
+def _cross_reference(q, kv, valid, h, d, g=None):
+    """f32 attention of q [N, Lq, E] over kv [N, Lk, 2E] (K | V); with ``g`` also the gradients of q and kv."""
+    N, Lq, E = q.shape
+    Lk = kv.shape[1]
+    qf, kvf = q.detach().float().requires_grad_(g is not None), kv.detach().float().requires_grad_(g is not None)
+    k, v = kvf.split(E, dim=-1)
+    qh = qf.reshape(N, Lq, h, d).transpose(1, 2)
+    kh, vh = [t.reshape(N, Lk, h, d).transpose(1, 2) for t in (k, v)]
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    o = (p @ vh).transpose(1, 2).reshape(N, Lq, E)
+    if g is None:
+        return o
+    o.backward(g.float())
+    return o, qf.grad, kvf.grad
+
+
+@pytest.mark.parametrize("N,h,Lq,Lk", [(3, 8, 40, 320), (2, 4, 300, 384), (5, 8, 257, 292), (2, 8, 384, 384), (4, 8, 1, 384), (2, 8, 64, 289 + 3)])
+def test_resident_kernels_with_separate_query_and_memory_tensors(N, h, Lq, Lk):
+    """The same kernels behind the cross-attention call form: q from its own [N, Lq, E] tensor, K | V packed in a [N, Lk, 2E] memory
+    projection (different row strides for q, k / v and the output), Lq != Lk -- query counts that fill only part of a wave group, the
+    shortest and the longest key counts the resident kernels take, masked keys.  Forward for every shape; the backward kernel takes
+    Lq > 256 (the others run the flash-style backward on the same forward output)."""
+    ops = _ops()
+    d, E = 64, h * 64
+    g0 = torch.Generator().manual_seed(Lq * 1000 + Lk)
+    q = (torch.randn(N, Lq, E, generator=g0) * 0.7).to(DEV).to(torch.bfloat16).requires_grad_()
+    kv = (torch.randn(N, Lk, 2 * E, generator=g0) * 0.7).to(DEV).to(torch.bfloat16).requires_grad_()
+    g = torch.randn(N, Lq, E, generator=g0).to(DEV).to(torch.bfloat16)
+    valid = torch.ones(N, Lk, dtype=torch.bool, device=DEV)
+    valid[0, Lk - 5:] = False
+    valid[N - 1] = (torch.rand(Lk, generator=g0) > 0.4).to(DEV)
+    o = ops.attention(q, kv, kv, 0, 0, E, h, d, key_valid=valid)
+    o.backward(g)
+    ref_o, ref_dq, ref_dkv = _cross_reference(q, kv, valid, h, d, g)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(q.grad.float()).all() and torch.isfinite(kv.grad.float()).all()
+    assert _rel(o, ref_o) < 6e-3
+    assert _rel(q.grad, ref_dq) < 1.2e-2
+    assert _rel(kv.grad[..., :E], ref_dkv[..., :E]) < 1.2e-2 and _rel(kv.grad[..., E:], ref_dkv[..., E:]) < 1.2e-2
