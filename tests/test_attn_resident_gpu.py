@@ -196,3 +196,22 @@ def test_resident_kernels_with_separate_query_and_memory_tensors(N, h, Lq, Lk):
     assert _rel(o, ref_o) < 6e-3
     assert _rel(q.grad, ref_dq) < 1.2e-2
     assert _rel(kv.grad[..., :E], ref_dkv[..., :E]) < 1.2e-2 and _rel(kv.grad[..., E:], ref_dkv[..., E:]) < 1.2e-2
+
+
+def test_resident_kernels_without_a_key_mask():
+    """key_valid = None (every key counts): forward and backward against the f32 reference."""
+    ops = _ops()
+    N, h, L, d = 3, 8, 352, 64
+    E = h * d
+    g0 = torch.Generator().manual_seed(99)
+    qkv = (torch.randn(N, L, 3 * E, generator=g0) * 0.7).to(DEV).to(torch.bfloat16).requires_grad_()
+    g = torch.randn(N, L, E, generator=g0).to(DEV).to(torch.bfloat16)
+    ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=None).backward(g)
+    valid = torch.ones(N, L, dtype=torch.bool, device=DEV)
+    with torch.no_grad():
+        o = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, h, d, key_valid=None)
+    ref_o, _ = _reference(qkv.detach(), valid, h, d)
+    ref = _grads_reference(qkv, valid, h, d, g)
+    assert _rel(o, ref_o) < 6e-3
+    for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+        assert _rel(qkv.grad.float()[..., sl], ref[..., sl]) < 1.2e-2, name
