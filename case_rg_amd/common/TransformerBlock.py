@@ -40,8 +40,8 @@ class TransformerBlock(nn.Module):
             n1, xres = ops.layer_norm_carry(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         else:
             n1, xres = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), x
-        r = self.self_attn.self_attention(n1, valid, residual=xres, p_res=0.1)
-        n2 = ops.layer_norm(r, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        # out-projection + dropout + residual -> LN2 as ONE op: its backward emits the dropout-masked gradient from the LayerNorm kernel
+        n2 = self.self_attn.self_attention(n1, valid, residual=xres, p_res=0.1, ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         y = ops.ffn(n2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                     self.activation, p_inner=p, p_out=0.0)
         y = ops.mask_rows(y, valid)

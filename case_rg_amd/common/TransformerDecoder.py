@@ -27,16 +27,18 @@ class TransformerDecoderLayer(nn.Module):
         self.p = dropout
         self.activation = _check_activation(activation)
 
-    def forward_batch_first(self, x, memory, tgt_valid=None, memory_valid=None, causal=True, memory_kv=None):
-        """x [N, T, E]; memory [N, S, E]; *_valid bool True = token."""
+    def forward_batch_first(self, x, memory, tgt_valid=None, memory_valid=None, causal=True, memory_kv=None, normed=False, next_norm=None):
+        """x [N, T, E]; memory [N, S, E]; *_valid bool True = token.  Every LayerNorm that follows an out-projection or the feed-forward pair
+        is part of that op (``ln=``: ops.linear / ops.ffn); ``normed`` / ``next_norm`` as in TransformerEncoderLayer.forward_batch_first."""
         p = config.drop_p(self.p, self.training)
-        x = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.self_attn.self_attention(x, tgt_valid, causal=causal, residual=x, p_res=self.p)
-        x = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x = self.multihead_attn.cross_attention(x, memory, memory_valid, residual=x, p_res=self.p, kv=memory_kv)
-        x = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        if not normed:
+            x = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.self_attn.self_attention(x, tgt_valid, causal=causal, residual=x, p_res=self.p,
+                                          ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
+        x = self.multihead_attn.cross_attention(x, memory, memory_valid, residual=x, p_res=self.p, kv=memory_kv,
+                                                ln=(self.norm3.weight, self.norm3.bias, self.norm3.eps))
         return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                       self.activation, p_inner=p, p_out=p, residual=x)
+                       self.activation, p_inner=p, p_out=p, residual=x, ln=next_norm)
 
     def step(self, x, t, self_kv, hist_valid, memory_kv, memory_valid):
         """Incremental decoding of position ``t`` (inference): x [N, 1, E]; ``self_kv`` [N, Tmax, 2E] holds the K/V
@@ -113,12 +115,13 @@ class TransformerDecoder(nn.Module):
 
     def forward_batch_first(self, x, memory, tgt_valid=None, memory_valid=None, causal=True, memory_kvs=None):
         # one alias of the memory per layer (each layer projects it to K / V): its gradient is then summed in one pass (ops.fanout)
-        mems = ops.fanout(memory, len(self.layers)) if memory_kvs is None else (memory,) * len(self.layers)
-        for i, layer in enumerate(self.layers):
-            x = layer.forward_batch_first(x, mems[i], tgt_valid, memory_valid, causal,
-                                          None if memory_kvs is None else memory_kvs[i])
-        if self.norm is not None:
-            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        layers = list(self.layers)
+        mems = ops.fanout(memory, len(layers)) if memory_kvs is None else (memory,) * len(layers)
+        tail = None if self.norm is None else (self.norm.weight, self.norm.bias, self.norm.eps)
+        for i, layer in enumerate(layers):
+            nxt = layers[i + 1].norm1 if i + 1 < len(layers) else None
+            x = layer.forward_batch_first(x, mems[i], tgt_valid, memory_valid, causal, None if memory_kvs is None else memory_kvs[i],
+                                          normed=i > 0, next_norm=tail if nxt is None else (nxt.weight, nxt.bias, nxt.eps))
         return x
 
     def project_memory(self, memory):

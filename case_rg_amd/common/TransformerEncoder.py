@@ -35,30 +35,31 @@ class TransformerEncoderLayer(nn.Module):
         self.p = dropout
         self.activation = _check_activation(activation)
 
-    def forward_batch_first(self, x, valid=None, causal=False):
-        """x [N, L, E]; valid [N, L] bool (True = token)."""
+    def forward_batch_first(self, x, valid=None, causal=False, normed=False, next_norm=None):
+        """x [N, L, E]; valid [N, L] bool (True = token).  ``normed``: x already is LN1(x) (the previous layer applied this layer's
+        norm1 behind its feed-forward, ``next_norm``); ``next_norm`` = (gamma, beta, eps) of the LayerNorm that follows this layer."""
         p = config.drop_p(self.p, self.training)
-        s = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        s = self.self_attn.self_attention(s, valid, causal=causal, residual=s, p_res=self.p)
-        s = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        s = x if normed else ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        s = self.self_attn.self_attention(s, valid, causal=causal, residual=s, p_res=self.p,
+                                          ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         return ops.ffn(s, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                       self.activation, p_inner=p, p_out=p, residual=s)
+                       self.activation, p_inner=p, p_out=p, residual=s, ln=next_norm)
 
-    def forward_rows(self, x, groups, valids):
+    def forward_rows(self, x, groups, valids, normed=False, next_norm=None):
         """The same layer over SEVERAL sequence groups at once: x [rows, E] holds the rows of all groups back to back
         (``groups`` = [(first row, sequences, length)]); everything row-local runs once, the attention core once per group."""
         p = config.drop_p(self.p, self.training)
         at = self.self_attn
-        s = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        s = x if normed else ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         if torch.is_grad_enabled() and s.requires_grad:
             qkv, res = ops.linear_carry(s, at.in_proj_weight, at.in_proj_bias)
         else:
             qkv, res = ops.linear(s, at.in_proj_weight, at.in_proj_bias), s
         ctx = ops.attention_groups(qkv, groups, valids, at.num_heads, at.head_dim, p_drop=config.drop_p(at.dropout, self.training))
-        s = ops.linear(ctx, at.out_proj.weight, at.out_proj.bias, residual=res, p_drop=config.drop_p(self.p, self.training))
-        s = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        s = ops.linear(ctx, at.out_proj.weight, at.out_proj.bias, residual=res, p_drop=config.drop_p(self.p, self.training),
+                       ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         return ops.ffn(s, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                       self.activation, p_inner=p, p_out=p, residual=s)
+                       self.activation, p_inner=p, p_out=p, residual=s, ln=next_norm)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
         """src [L, N, E] (sequence first, as the reference); src_key_padding_mask [N, L] True = pad."""
@@ -96,10 +97,20 @@ class TransformerEncoder(nn.Module):
                 and all(l.self_attn.embed_dim == 512 and l.linear1.out_features == 512 and l.self_attn.head_dim == 64 for l in self.layers)):
             x = self._chained(x, valid)
         else:
-            for layer in self.layers:
-                x = layer.forward_batch_first(x, valid, causal)
+            return self._layers(x, lambda layer, h, normed, nxt: layer.forward_batch_first(h, valid, causal, normed, nxt))
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+    def _layers(self, x, run):
+        """The layer loop with every LayerNorm that follows a feed-forward pair -- the next layer's norm1, the stack's final norm -- made
+        part of that pair's op (ops.ffn(ln=...)): in training its backward then hands the dropout-masked gradient to the pair's GEMMs
+        from the LayerNorm kernel instead of a separate pass."""
+        layers = list(self.layers)
+        tail = None if self.norm is None else (self.norm.weight, self.norm.bias, self.norm.eps)
+        for i, layer in enumerate(layers):
+            nxt = layers[i + 1].norm1 if i + 1 < len(layers) else None
+            x = run(layer, x, i > 0, tail if nxt is None else (nxt.weight, nxt.bias, nxt.eps))
         return x
 
     def rows_supported(self, dtype, needs_grad):
@@ -108,11 +119,7 @@ class TransformerEncoder(nn.Module):
 
     def forward_rows(self, x, groups, valids):
         """x [rows, E]: several sequence groups back to back (see TransformerEncoderLayer.forward_rows)."""
-        for layer in self.layers:
-            x = layer.forward_rows(x, groups, valids)
-        if self.norm is not None:
-            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        return x
+        return self._layers(x, lambda layer, h, normed, nxt: layer.forward_rows(h, groups, valids, normed, nxt))
 
     def forward(self, src, mask=None, src_key_padding_mask=None):
         valid = None if src_key_padding_mask is None else ~src_key_padding_mask

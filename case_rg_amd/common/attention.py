@@ -34,8 +34,9 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.out_proj.weight)
 
     # -- batch-first cores --------------------------------------------------------------------
-    def self_attention(self, x, key_valid=None, causal=False, residual=None, p_res=0.0):
-        """x [N, L, E] -> out_proj(attention(x)) (+ dropout, + residual)."""
+    def self_attention(self, x, key_valid=None, causal=False, residual=None, p_res=0.0, ln=None):
+        """x [N, L, E] -> out_proj(attention(x)) (+ dropout, + residual); ``ln`` = (gamma, beta, eps): the LayerNorm that follows, as part
+        of the out-projection op (ops.linear)."""
         E = self.embed_dim
         if residual is x and torch.is_grad_enabled() and x.requires_grad:
             # x + out_proj(attention(in_proj(x))): both gradients of x meet in the in-projection's dX GEMM
@@ -45,15 +46,15 @@ class MultiheadAttention(nn.Module):
         ctx = ops.attention(qkv, qkv, qkv, 0, E, 2 * E, self.num_heads, self.head_dim, key_valid=key_valid, causal=causal,
                             p_drop=config.drop_p(self.dropout, self.training))
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
-                          p_drop=config.drop_p(p_res, self.training))
+                          p_drop=config.drop_p(p_res, self.training), ln=ln)
 
     def project_memory(self, memory):
         """K/V projection of a memory [N, S, E] -> packed [N, S, 2E] (cacheable across decode steps)."""
         E = self.embed_dim
         return ops.linear(memory, self.in_proj_weight[E:], self.in_proj_bias[E:])
 
-    def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None):
-        """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention)."""
+    def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None, ln=None):
+        """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention); ``ln``: see self_attention."""
         E = self.embed_dim
         q = ops.linear(x, self.in_proj_weight[:E], self.in_proj_bias[:E])
         if kv is None:
@@ -61,7 +62,7 @@ class MultiheadAttention(nn.Module):
         ctx = ops.attention(q, kv, kv, 0, 0, E, self.num_heads, self.head_dim, key_valid=memory_valid,
                             p_drop=config.drop_p(self.dropout, self.training))
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
-                          p_drop=config.drop_p(p_res, self.training))
+                          p_drop=config.drop_p(p_res, self.training), ln=ln)
 
     # -- nn.MultiheadAttention-compatible call (sequence-first) ---------------------------------
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):

@@ -268,18 +268,52 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_guarded_kernel(const T* __rest
   }
 }
 
+// Optional SECOND output of the vector backward kernels (case_layernorm_bwd_dropout): the LayerNorm's input was y = dropout(x W^T + b) + r,
+// so the Linear's backward needs mask * dx / (1 - p) next to dx itself (which is the gradient of r).  Written here, from the registers that
+// hold dx, it costs one store; as the separate case_dropout pass it replaces it cost a read and a store of the whole tensor.  The mask is
+// case_dropout's: element index = row * cols + column behind (seed, offset), applied to dx AFTER its rounding to T (what the separate
+// pass read), so both forms produce the same bits.
+struct LnDrop {
+  void* out;
+  float p;
+  uint64_t seed, offset;
+};
+template <typename T>
+__device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, const float (&o)[Vec16<T>::N]) {
+  constexpr int E = Vec16<T>::N;
+  float q[E];
+  if constexpr (sizeof(T) == 2) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(o[2 * i], o[2 * i + 1]);
+    Vec16<T>::unpack(make_uint4(w[0], w[1], w[2], w[3]), q);
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) q[e] = o[e];
+  }
+  const float scale = 1.f / (1.f - dr.p);
+#pragma unroll
+  for (int e = 0; e < E; e += 2) {  // idx is a multiple of E: even
+    float u0, u1;
+    rng_uniform2(dr.seed, dr.offset + (uint64_t)(idx + e), u0, u1);
+    q[e] = u0 >= dr.p ? q[e] * scale : 0.f;
+    q[e + 1] = u1 >= dr.p ? q[e + 1] * scale : 0.f;
+  }
+  Vec16<T>::store(reinterpret_cast<T*>(dr.out) + idx, q);
+}
+
 // Backward.  One wave per row, the row in registers; the raw 16-byte vectors of the wave's NEXT row (x, dy and the optional
 // x2 / dx_add streams) are requested before the current row's reductions, so every wave keeps two rows of loads in flight:
 // the row is a dependent chain (load -> two wave reductions -> store) and with one row in flight per wave the kernel ran at
 // 1.4-1.7 TB/s on streams that do not fit the Infinity Cache (copy ceiling 6.3 TB/s).  The loop body is branch-free (cols ==
 // NV * 64 * E, optional streams are template flags): behind a conditional load hipcc waits vmcnt(0) and drains the prefetch.
-template <typename T, int NV, bool HAS_X2, bool HAS_ADD>
+template <typename T, int NV, bool HAS_X2, bool HAS_ADD, bool DROP2 = false>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ x2, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          T* __restrict__ dx, const T* __restrict__ dx_add,
                                                          float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
-                                                         int64_t cols) {
+                                                         int64_t cols, const LnDrop dr = LnDrop()) {
   constexpr int E = Vec16<T>::N;
   extern __shared__ float part[];  // [4 waves][2][cols] column partials, summed and added to d_gamma / d_beta at the end
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -356,6 +390,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
         for (int e = 0; e < E; ++e) o[e] += w[e];
       }
       Vec16<T>::store(dx + r * cols + ((int64_t)i * 64 + lane) * E, o);
+      if constexpr (DROP2) ln_store_dropped<T>(dr, r * cols + ((int64_t)i * 64 + lane) * E, o);
     }
     cur = nxt;
   }
@@ -383,13 +418,13 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
 // wave per SIMD, 1.7 TB/s.  Here a workgroup of NW waves shares each row: wave w owns columns [512 w, 512 w + 512) (8 per
 // lane), the two row statistics are combined through LDS (R rows per barrier, slots double-buffered -> one barrier per
 // group), and the loads of the next group are requested before the barrier.  ~70 registers, 4+ workgroups per CU.
-template <typename T, int R, bool HAS_X2, bool HAS_ADD>
+template <typename T, int R, bool HAS_X2, bool HAS_ADD, bool DROP2 = false>
 __global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ x2, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            T* __restrict__ dx, const T* __restrict__ dx_add,
                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
-                                                           int64_t cols) {
+                                                           int64_t cols, const LnDrop dr = LnDrop()) {
   constexpr int E = Vec16<T>::N;
   __shared__ float part[2][R][8][2];  // [buffer][row of the group][wave][s1, s2]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -481,6 +516,7 @@ __global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__
           for (int e = 0; e < E; ++e) o[e] += w[e];
         }
         Vec16<T>::store(dx + (row0 + j) * cols + col, o);
+        if constexpr (DROP2) ln_store_dropped<T>(dr, (row0 + j) * cols + col, o);
       }
     }
     cur = nxt;
@@ -805,6 +841,50 @@ extern "C" int case_layernorm_fwd(const void* x, const void* x2, const float* ga
     hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)x, (const bf16_t*)x2,
                        gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps);
   return case_check_launch("case_layernorm_fwd");
+}
+
+// the dual-output form: full 64-lane chunks only (cols = nv * 64 * E, nv <= 8), no second input, no carried gradient
+template <typename T>
+bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dg,
+                        float* db, int64_t rows, int64_t cols, const LnDrop& dr, hipStream_t s) {
+  constexpr int E = Vec16<T>::N;
+  const int nv = (int)((cols + 64 * E - 1) / (64 * E));
+  if (cols != (int64_t)nv * 64 * E || nv > 8) return false;
+  const T* nul = nullptr;
+  if (nv >= 3) {
+    constexpr int R = 2;
+    const int grid = grid_for(rows, 1, R * 16, 256 * 4);
+    hipLaunchKernelGGL((ln_bwd_split_kernel<T, R, false, false, true>), dim3(grid), dim3(64 * nv), 2 * cols * sizeof(float), s, (const T*)dy,
+                       (const T*)x, nul, gamma, mean, rstd, (T*)dx, nul, dg, db, rows, cols, dr);
+    return true;
+  }
+  const int grid = grid_for(rows, 4, 8, 256 * 8);
+  const size_t lds = 8 * cols * sizeof(float);
+  if (nv == 1)
+    hipLaunchKernelGGL((ln_bwd_vec_kernel<T, 1, false, false, true>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, nul, gamma, mean,
+                       rstd, (T*)dx, nul, dg, db, rows, cols, dr);
+  else
+    hipLaunchKernelGGL((ln_bwd_vec_kernel<T, 2, false, false, true>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, nul, gamma, mean,
+                       rstd, (T*)dx, nul, dg, db, rows, cols, dr);
+  return true;
+}
+
+extern "C" int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                          void* dx_dropped, float* d_gamma, float* d_beta, int64_t rows, int64_t cols, float p, uint64_t seed,
+                                          uint64_t offset, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_dropped && d_gamma && d_beta && rows > 0 && cols > 0 && p > 0.f && p < 1.f,
+               "case_layernorm_bwd_dropout: bad argument");
+  const LnDrop dr = {dx_dropped, p, seed, offset};
+  hipStream_t s = (hipStream_t)stream;
+  bool ok = false;
+  if (dtype == CASE_F32 && ln_vec_ok<float>(dy, x, dx, cols) && ln_vec_ok<float>(dx_dropped, nullptr, nullptr, cols))
+    ok = ln_bwd_drop_launch<float>(dy, x, gamma, mean, rstd, dx, d_gamma, d_beta, rows, cols, dr, s);
+  else if (dtype == CASE_BF16 && ln_vec_ok<bf16_t>(dy, x, dx, cols) && ln_vec_ok<bf16_t>(dx_dropped, nullptr, nullptr, cols))
+    ok = ln_bwd_drop_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, d_gamma, d_beta, rows, cols, dr, s);
+  if (!ok)
+    return case_set_error(CASE_E_UNSUPPORTED, "case_layernorm_bwd_dropout: needs 16-byte aligned rows of a whole number of 64-lane chunks "
+                                              "(cols = %d x k, k <= 8); run case_layernorm_bwd + case_dropout", dtype == CASE_BF16 ? 512 : 256);
+  return case_check_launch("case_layernorm_bwd_dropout");
 }
 
 extern "C" int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,

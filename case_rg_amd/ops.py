@@ -431,13 +431,52 @@ def _input_grad(g, wc, M, K, N):
     return dx
 
 
+LN_TAIL = os.environ.get("CASE_LN_TAIL", "1") != "0"  # A/B switch: "0" keeps Linear / FFN and the LayerNorm behind them separate ops
+
+
+def _ln_tail_forward(y2, ln):
+    """LayerNorm of the rows y2 [M, N] right behind the GEMM that produced them (same kernel as ops.layer_norm)."""
+    gamma, beta, eps = ln
+    n = torch.empty_like(y2)
+    mean = torch.empty(y2.shape[0], dtype=torch.float32, device=y2.device)
+    rstd = torch.empty_like(mean)
+    g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+    A.call("case_layernorm_fwd", _ptr(y2), None, _ptr(g), _ptr(b), _ptr(n), _ptr(mean), _ptr(rstd), y2.shape[0], y2.shape[1], eps,
+           _code(y2), _stream())
+    return n, g, mean, rstd
+
+
+def _ln_tail_backward(dn, y2, g, mean, rstd, drop):
+    """Backward of LN(y), y = dropout(z) + r: -> (dy, masked dy, d_gamma, d_beta).  dy is the gradient of y (and of the residual r); the masked
+    copy -- what the GEMMs of z's Linear read -- comes out of the SAME kernel when it has a dropout (case_layernorm_bwd_dropout) instead of a
+    separate pass over dy."""
+    R, C = y2.shape
+    dn2 = dn.reshape(R, C)
+    dn2 = dn2 if dn2.is_contiguous() else dn2.contiguous()
+    if dn2.dtype != y2.dtype:
+        dn2 = cast(dn2, y2.dtype)
+    dy = torch.empty_like(y2)
+    dg, db = _zeros_like_shapes(y2.device, (C,), (C,))
+    chunk = 512 if y2.dtype == torch.bfloat16 else 256
+    if drop is not None and C % chunk == 0 and C // chunk <= 8:
+        gm = torch.empty_like(y2)
+        A.call("case_layernorm_bwd_dropout", _ptr(dn2), _ptr(y2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(gm), _ptr(dg), _ptr(db), R, C,
+               drop[0], drop[1], drop[2], _code(y2), _stream())
+        return dy, gm, dg, db
+    A.call("case_layernorm_bwd", _ptr(dn2), _ptr(y2), None, _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), None, _ptr(dg), _ptr(db), R, C,
+           _code(y2), _stream())
+    return dy, (_dropout_raw(dy, *drop) if drop is not None else dy), dg, db
+
+
 class LinearFn(Function):
     """y = dropout(x W^T + b) + residual.  With ``carry`` the input is handed back as a second output: a caller that adds x
     to something computed from y (x + out_proj(attention(in_proj(x)))) takes its residual from that output, and both
     gradients of x then arrive here together -- the sum rides in the epilogue of the dX GEMM instead of a separate add."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, p_drop, out_dtype, carry=False):
+    def forward(ctx, x, w, b, residual, p_drop, out_dtype, carry=False, ln_g=None, ln_b=None, ln_eps=0.0):
+        """``ln_g`` / ``ln_b`` / ``ln_eps``: a LayerNorm applied to the result (its only consumer); the backward then produces the
+        LayerNorm's input gradient and its dropout-masked copy in one kernel (_ln_tail_backward)."""
         K, N = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, K)
         if not x2.is_contiguous():
@@ -455,24 +494,36 @@ class LinearFn(Function):
             res2 = residual.reshape(M, N).contiguous()
             epi |= A.EPI_RESIDUAL
         gemm(x2, wc, y, M, N, K, K, K, N, epilogue=epi, bias_col=b, aux=res2, ld_aux=N, drop=drop)
-        ctx.save_for_backward(x2, wc)
         ctx.meta = (x.shape, b is not None, residual is not None, drop, w.dtype)
+        if ln_g is not None:
+            n, g_, mean, rstd = _ln_tail_forward(y, (ln_g, ln_b, ln_eps))
+            ctx.save_for_backward(x2, wc, y, g_, mean, rstd)
+            return n.view(*x.shape[:-1], N)
+        ctx.save_for_backward(x2, wc)
         if carry:
             return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy, d_carry=None):
-        x2, wc = ctx.saved_tensors
         xshape, has_b, has_res, drop, _ = ctx.meta
-        M, K = x2.shape
-        N = wc.shape[0]
-        d_res = dy if has_res else None
-        g = cast(dy.reshape(M, N), x2.dtype)
-        if not g.is_contiguous():
-            g = g.contiguous()
-        if drop is not None:
-            g = _dropout_raw(g, *drop)
+        d_lng = d_lnb = None
+        if len(ctx.saved_tensors) == 6:  # a LayerNorm behind the GEMM: dy arrives as the gradient of its output
+            x2, wc, y, g_, mean, rstd = ctx.saved_tensors
+            M, K = x2.shape
+            N = wc.shape[0]
+            dy, g, d_lng, d_lnb = _ln_tail_backward(dy, y, g_, mean, rstd, drop)
+            d_res = dy.view(*xshape[:-1], N) if has_res else None
+        else:
+            x2, wc = ctx.saved_tensors
+            M, K = x2.shape
+            N = wc.shape[0]
+            d_res = dy if has_res else None
+            g = cast(dy.reshape(M, N), x2.dtype)
+            if not g.is_contiguous():
+                g = g.contiguous()
+            if drop is not None:
+                g = _dropout_raw(g, *drop)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if d_carry is not None and d_carry.dtype == x2.dtype:
@@ -493,7 +544,7 @@ class LinearFn(Function):
             dw = _weight_grad(g, x2, N, K)
         elif want_b:
             db = _colsum(g)
-        return dx, dw, db, d_res, None, None, None
+        return dx, dw, db, d_res, None, None, None, d_lng, d_lnb, None
 
 
 class RowDotFn(Function):
@@ -530,7 +581,12 @@ def linear_carry(x, w, b=None):
     return LinearFn.apply(x, w, b, None, 0.0, None, True)
 
 
-def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None):
+def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None, ln=None):
+    """``ln`` = (gamma, beta, eps): LayerNorm of the result, as part of this op (the caller must not use the un-normed result)."""
+    if ln is not None:
+        if LN_TAIL and out_dtype is None:
+            return LinearFn.apply(x, w, b, residual, p_drop, None, False, ln[0], ln[1], ln[2])
+        return layer_norm(linear(x, w, b, residual, p_drop, out_dtype), ln[0], ln[1], ln[2])
     if w.shape[0] == 1 and residual is None and p_drop == 0.0 and out_dtype in (None, torch.float32) and (
             out_dtype is torch.float32 or x.dtype == torch.float32):
         return RowDotFn.apply(x, w, b)  # single-output heads: a row dot, not an N = 1 GEMM tile
@@ -543,7 +599,7 @@ def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None):
 # ----------------------------------------------------------------------------------------------
 class FFNFn(Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act, p_inner, p_out, residual):
+    def forward(ctx, x, w1, b1, w2, b2, act, p_inner, p_out, residual, ln_g=None, ln_b=None, ln_eps=0.0):
         K, F_, N = x.shape[-1], w1.shape[0], w2.shape[0]
         x2 = x.reshape(-1, K)
         if not x2.is_contiguous():
@@ -565,25 +621,39 @@ class FFNFn(Function):
             res2 = residual.reshape(M, N).contiguous()
             epi |= A.EPI_RESIDUAL
         gemm(a, w2c, y, M, N, F_, F_, F_, N, epilogue=epi, bias_col=b2, aux=res2, ld_aux=N, drop=drop_o)
-        ctx.save_for_backward(x2, w1c, w2c, a, z)
         # y = x + FFN(x): the residual gradient can ride in the epilogue of the dX GEMM instead of a separate add
         ctx.meta = (x.shape, act, drop_i, drop_o, residual is not None, residual is x and N == K)
+        if ln_g is not None:  # a LayerNorm behind the pair (the next layer's norm1): see LinearFn
+            n, g_, mean, rstd = _ln_tail_forward(y, (ln_g, ln_b, ln_eps))
+            ctx.save_for_backward(x2, w1c, w2c, a, z, y, g_, mean, rstd)
+            return n.view(*x.shape[:-1], N)
+        ctx.save_for_backward(x2, w1c, w2c, a, z)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1c, w2c, a, z = ctx.saved_tensors
         xshape, act, drop_i, drop_o, has_res, res_is_x = ctx.meta
-        M, K = x2.shape
-        F_, N = w1c.shape[0], w2c.shape[0]
-        g = dy.reshape(M, N)
-        if not g.is_contiguous():
-            g = g.contiguous()
-        fuse_res = res_is_x and ctx.needs_input_grad[0] and g.dtype == x2.dtype
-        d_res = dy if (has_res and not fuse_res) else None
-        g_res = g  # the incoming gradient before the output dropout mask is applied
-        if drop_o is not None:
-            g = _dropout_raw(g, *drop_o)
+        d_lng = d_lnb = None
+        if len(ctx.saved_tensors) == 9:
+            x2, w1c, w2c, a, z, y, g_, mean, rstd = ctx.saved_tensors
+            M, K = x2.shape
+            F_, N = w1c.shape[0], w2c.shape[0]
+            g_res, g, d_lng, d_lnb = _ln_tail_backward(dy, y, g_, mean, rstd, drop_o)
+            dy = g_res.view(*xshape[:-1], N)
+            fuse_res = res_is_x and ctx.needs_input_grad[0]
+            d_res = dy if (has_res and not fuse_res) else None
+        else:
+            x2, w1c, w2c, a, z = ctx.saved_tensors
+            M, K = x2.shape
+            F_, N = w1c.shape[0], w2c.shape[0]
+            g = dy.reshape(M, N)
+            if not g.is_contiguous():
+                g = g.contiguous()
+            fuse_res = res_is_x and ctx.needs_input_grad[0] and g.dtype == x2.dtype
+            d_res = dy if (has_res and not fuse_res) else None
+            g_res = g  # the incoming gradient before the output dropout mask is applied
+            if drop_o is not None:
+                g = _dropout_raw(g, *drop_o)
         dw1, db1, dw2, db2 = _zeros_like_shapes(g.device, (F_, K), (F_,), (N, F_), (N,))
         _weight_grad(g, a, N, F_, out=dw2, bias_out=db2)
         # dz = (g W2) * act'(.) * keep_i/(1-p_i): one GEMM with the derivative (and the regenerated mask) in the epilogue
@@ -601,10 +671,15 @@ class FFNFn(Function):
             else:
                 gemm(dz, w1c, dx, M, K, F_, F_, K, K, b_kmajor=True)
             dx = dx.view(xshape)
-        return dx, dw1, db1, dw2, db2, None, None, None, d_res
+        return dx, dw1, db1, dw2, db2, None, None, None, d_res, d_lng, d_lnb, None
 
 
-def ffn(x, w1, b1, w2, b2, act, p_inner=0.0, p_out=0.0, residual=None):
+def ffn(x, w1, b1, w2, b2, act, p_inner=0.0, p_out=0.0, residual=None, ln=None):
+    """``ln`` = (gamma, beta, eps): LayerNorm of the result as part of this op (see ``linear``)."""
+    if ln is not None:
+        if LN_TAIL:
+            return FFNFn.apply(x, w1, b1, w2, b2, act, p_inner, p_out, residual, ln[0], ln[1], ln[2])
+        return layer_norm(FFNFn.apply(x, w1, b1, w2, b2, act, p_inner, p_out, residual), ln[0], ln[1], ln[2])
     return FFNFn.apply(x, w1, b1, w2, b2, act, p_inner, p_out, residual)
 
 

@@ -181,6 +181,14 @@ int case_layernorm_fwd(const void* x, const void* x2, const float* gamma, const 
 int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* gamma, const float* mean,
                        const float* rstd, void* dx, const void* dx_add, float* d_gamma, float* d_beta, int64_t rows,
                        int64_t cols, int32_t dtype, case_stream_t stream);
+/* The backward of LN(dropout(x W^T + b) + r) -- out-projection / feed-forward followed by a LayerNorm, common/TransformerEncoder.py:68-69,
+ * 72-75, common/TransformerBlock.py:27-28 -- with TWO outputs: dx (the gradient of the LayerNorm's input = of the residual r) and
+ * dx_dropped = mask * dx / (1 - p), the gradient of the Linear's pre-dropout output that its dX / dW GEMMs read.  The mask is case_dropout's
+ * (element index row * cols + column behind (seed, offset)) applied to the ROUNDED dx: the same bits as case_layernorm_bwd followed by
+ * case_dropout, one tensor pass less.  Rows of k x 64 lanes x 16 bytes (k <= 8), no x2 / dx_add; CASE_E_UNSUPPORTED otherwise. */
+int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                               void* dx_dropped, float* d_gamma, float* d_beta, int64_t rows, int64_t cols, float p, uint64_t seed,
+                               uint64_t offset, int32_t dtype, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4/K5/K6 (softmax stage) and the masked softmaxes of K7/K8/K10/K11

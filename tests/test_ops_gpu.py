@@ -766,6 +766,73 @@ def test_weight_gradient_gemm_also_sums_the_bias_gradient():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cols_k", [1, 2, 5])
+def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_for_bit(dt, cols_k):
+    """case_layernorm_bwd_dropout: dx and mask * dx / (1 - p) from one kernel == case_layernorm_bwd followed by case_dropout (same bits:
+    the mask is applied to the rounded dx), for the one-wave-per-row kernels (k = 1, 2) and the row-split kernel (k = 5: the 5H rows)."""
+    ops = _ops()
+    from case_rg_amd import _abi as A
+    rows, cols = 77, cols_k * (256 if dt == torch.float32 else 512)
+    x, dy = _rand(rows, cols, dt=dt, seed=1), _rand(rows, cols, dt=dt, seed=2)
+    gamma = _rand(cols, seed=3) + 1.0
+    mean, rstd = x.float().mean(1).contiguous(), (x.float().var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    code = A.F32 if dt == torch.float32 else A.BF16
+    p, seed, off = 0.1, 1234567, 4242
+    dx0, dg0, db0 = torch.empty_like(x), torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+    A.call("case_layernorm_bwd", dy.data_ptr(), x.data_ptr(), None, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx0.data_ptr(), None,
+           dg0.data_ptr(), db0.data_ptr(), rows, cols, code, 0)
+    g0 = torch.empty_like(x)
+    A.call("case_dropout", dx0.data_ptr(), g0.data_ptr(), x.numel(), p, seed, off, code, 0)
+    dx1, g1, dg1, db1 = torch.empty_like(x), torch.empty_like(x), torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+    A.call("case_layernorm_bwd_dropout", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx1.data_ptr(),
+           g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols, p, seed, off, code, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1), "dx differs"
+    assert torch.equal(g0, g1), "masked copy differs"
+    assert 0.05 < (g1 == 0).float().mean().item() < 0.16
+    _close(dg1, dg0, 1e-5, "d_gamma")
+    _close(db1, db0, 1e-5, "d_beta")
+    with pytest.raises(RuntimeError, match="64-lane"):
+        A.call("case_layernorm_bwd_dropout", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx1.data_ptr(),
+               g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols - 8, p, seed, off, code, 0)
+
+
+@pytest.mark.parametrize("which", ["linear", "ffn"])
+def test_layernorm_as_the_tail_of_linear_and_ffn_equals_the_separate_ops(which):
+    """ops.linear(ln=...) / ops.ffn(ln=...): identical forward, and gradients equal to the composition with ops.layer_norm (the backward
+    differs only in WHERE the dropout-masked gradient is produced), with dropout on and the residual forms the layers use."""
+    from case_rg_amd import config
+    ops = _ops()
+    dt = torch.bfloat16
+    M, K = 384, 512
+    x0 = _rand(M, K, dt=dt, seed=1)
+    w1, b1, w2, b2 = _rand(512, K, seed=2, scale=K ** -0.5), _rand(512, seed=3), _rand(512, 512, seed=4, scale=512 ** -0.5), _rand(512, seed=5)
+    gam, bet = _rand(512, seed=6) + 1.0, _rand(512, seed=7)
+    gout = _rand(M, 512, dt=dt, seed=8)
+    config.set_dropout(True)
+    try:
+        res = {}
+        for fused in (True, False):
+            config.manual_seed(5)
+            ops.LN_TAIL = fused
+            leaves = [t.clone().requires_grad_(True) for t in (x0, w1, b1, w2, b2, gam, bet)]
+            x, a1, c1, a2, c2, g, b = leaves
+            if which == "linear":
+                y = ops.linear(x, a1, c1, residual=x, p_drop=0.1, ln=(g, b, 1e-5))
+            else:
+                y = ops.ffn(x, a1, c1, a2, c2, "gelu", p_inner=0.1, p_out=0.1, residual=x, ln=(g, b, 1e-5))
+            y.backward(gout)
+            res[fused] = [y.detach()] + [t.grad for t in leaves if t.grad is not None]
+        assert torch.equal(res[True][0], res[False][0]), "forward differs"
+        assert len(res[True]) == len(res[False])
+        for a, b in zip(res[True][1:], res[False][1:]):
+            _close(a, b, 2e-3, "%s gradient with the LayerNorm tail" % which)
+    finally:
+        ops.LN_TAIL = True
+        config.set_dropout(False)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_fanout_sums_the_gradients_of_its_aliases_in_one_launch(dt):
     """ops.fanout / case_add_n: n aliases for n consumers, ONE summing kernel in backward (f32 accumulation, one rounding); falls back to
     plain adds for what the kernel does not take (odd sizes), is the identity without gradients."""
