@@ -56,9 +56,13 @@ class MultiheadAttention(nn.Module):
     def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None, ln=None):
         """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention); ``ln``: see self_attention."""
         E = self.embed_dim
-        q = ops.linear(x, self.in_proj_weight[:E], self.in_proj_bias[:E])
         if kv is None:
-            kv = self.project_memory(memory)
+            # both halves of the packed in-projection are used here: one gradient concatenation instead of two zero-filled slices + an add
+            (wq, wkv), (bq, bkv) = ops.split_param_rows(self.in_proj_weight, E), ops.split_param_rows(self.in_proj_bias, E)
+            q = ops.linear(x, wq, bq)
+            kv = ops.linear(memory, wkv, bkv)
+        else:
+            q = ops.linear(x, self.in_proj_weight[:E], self.in_proj_bias[:E])
         ctx = ops.attention(q, kv, kv, 0, 0, E, self.num_heads, self.head_dim, key_valid=memory_valid,
                             p_drop=config.drop_p(self.dropout, self.training))
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,

@@ -1283,6 +1283,38 @@ class FanOutFn(Function):
         return add_n(gs), None
 
 
+class SplitParamRowsFn(Function):
+    """(w[:k], w[k:]) of a parameter used in two places (the query rows and the key / value rows of a cross-attention's packed
+    in-projection, common/TransformerDecoder.py:81 through nn.MultiheadAttention): the two gradients arrive together and are
+    concatenated by ONE launch.  Plain slicing costs five per parameter and step: autograd zero-fills a full-size tensor for each
+    slice, copies the slice's gradient in, and adds the two."""
+
+    @staticmethod
+    def forward(ctx, w, k):
+        k = int(k)
+        ctx.k, ctx.shape = k, w.shape
+        return w[:k], w[k:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        k, shape = ctx.k, ctx.shape
+        ref = g0 if g0 is not None else g1
+        if ref is None:
+            return None, None
+        if g0 is None:
+            g0 = torch.zeros((k,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
+        if g1 is None:
+            g1 = torch.zeros((shape[0] - k,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
+        return torch.cat([g0, g1], dim=0), None
+
+
+def split_param_rows(w, k):
+    k = int(k)
+    if not (torch.is_grad_enabled() and w.requires_grad):
+        return w[:k], w[k:]
+    return SplitParamRowsFn.apply(w, k)
+
+
 def fanout(x, n):
     """``n`` aliases of ``x`` whose gradients are summed in one pass (identity when gradients are off or the switch is)."""
     if n < 2 or not FANOUT or not (torch.is_grad_enabled() and x.requires_grad):
