@@ -64,6 +64,7 @@ SIGNATURES = {
     "case_layernorm_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, f32, i32, ptr],
     "case_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_layernorm_bwd_dropout": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, f32, u64, u64, i32, ptr],
+    "case_layernorm_bwd_concat5": [ptr] * 15 + [i64, i64, i32, ptr],
     "case_softmax_fwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr, ptr, ptr],
     "case_softmax_bwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr],
     "case_attention_supported": [i64],

@@ -54,8 +54,8 @@ class Interaction(nn.Module):
         B1_a, B1_g = ops.fanout(ops.bmm(Bt_1, Ep_b1, b_is_kn=True), 2)   # [n, Lq, H]
         A2 = ops.bmm(A_2, B1_a, b_is_kn=True)
         B2 = ops.bmm(Bt_2, A1_b, b_is_kn=True)
-        G_q_p = ops.concat5(Ep_g, A1_g, A2, pv).reshape(B, P, Lp, 5 * H)
-        G_p_q = ops.concat5(Eq_g, B1_g, B2, qv).reshape(B, P, Lq, 5 * H)
+        G_q_p = ops.concat5(Ep_g, A1_g, A2, pv, shape=(B, P, Lp, 5 * H))
+        G_p_q = ops.concat5(Eq_g, B1_g, B2, qv, shape=(B, P, Lq, 5 * H))
         if nq != P:
             G_p_q = ops.max_over_p(G_p_q)
         return G_p_q, G_q_p

@@ -36,8 +36,13 @@ class TransformerBlock(nn.Module):
         valid = input_mask.reshape(B * N, L)
         p = config.drop_p(0.1, self.training)
         if torch.is_grad_enabled() and x.requires_grad:
-            # x + MHA(LN(x)): the residual gradient of x is added inside the LayerNorm backward kernel
-            n1, xres = ops.layer_norm_carry(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            # x + MHA(LN(x)): the residual gradient of x is added inside the LayerNorm backward kernel; when x is the Interaction's
+            # concatenation itself, that kernel also runs the concatenation's backward (the 5H-wide gradient is never written)
+            fused = ops.concat5_layer_norm_carry(input, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            if fused is not None:
+                n1, xres = fused[0].reshape(B * N, L, E), fused[1].reshape(B * N, L, E)
+            else:
+                n1, xres = ops.layer_norm_carry(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         else:
             n1, xres = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), x
         # out-projection + dropout + residual -> LN2 as ONE op: its backward emits the dropout-masked gradient from the LayerNorm kernel

@@ -1,6 +1,8 @@
 // K2 LayerNorm and the masked row softmax (softmax stage of K4/K5/K6 and of K7/K8/K10/K11).
 // HBM-bound row kernels: one wave (C <= 1024) or one 256-thread workgroup per row, grid-stride over rows,
 // wavefront shuffles for the reductions, f32 statistics regardless of the storage dtype.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -867,6 +869,138 @@ bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const
     hipLaunchKernelGGL((ln_bwd_vec_kernel<T, 2, false, false, true>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, nul, gamma, mean,
                        rstd, (T*)dx, nul, dg, db, rows, cols, dr);
   return true;
+}
+
+// LayerNorm backward of the 5H rows G = [E | A1 | A2 | E o A1 | E o A2] (common/Interaction.py:65-72 -> common/TransformerBlock.py:25) FUSED with the
+// backward of that concatenation:
+//     dE = dG0 + dG3 o A1 + dG4 o A2,   dA1 = dG1 + dG3 o E,   dA2 = dG2 + dG4 o E        (0 on padded rows; dG rounded to bf16 first,
+// as the two-kernel path stores it) -- dG is never written: 630 MB less to write and 630 MB less to read per call at cfg 2.
+// ONE WAVE PER ROW and no barrier in the row loop: lane l owns columns 8 l .. 8 l + 7 of EVERY piece, so the concatenation's backward is
+// lane-local and the only cross-lane traffic is the two row sums.  15 vectors per lane and row in flight (x, dy, dx_add of five pieces);
+// the per-lane gamma / beta partial sums (80 registers) leave no room for a prefetched second row (256 registers, one wave per SIMD) and
+// it does not need one: 0.48 ms at 122 880 rows = 4.7 TB/s, against 0.88 ms for case_layernorm_bwd + case_concat5_bwd.  (A row-split
+// form -- five waves per row, pieces exchanged through LDS, two barriers per row pair -- ran at 2.2 TB/s: 1.02 ms.)  gamma sits in LDS.
+typedef float f32x4_r __attribute__((ext_vector_type(4)));
+template <bool HAS_ADD>
+__global__ __launch_bounds__(256) void ln_bwd_concat5_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
+                                                                  const uint8_t* __restrict__ row_valid, bf16_t* __restrict__ de,
+                                                                  bf16_t* __restrict__ da1, bf16_t* __restrict__ da2,
+                                                                  float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows) {
+  typedef bf16_t T;
+  constexpr int E = 8, H = 512, COLS = 5 * H;
+  __shared__ float sh[2 * COLS];  // gamma during the row loop (first half), the column sums afterwards
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < COLS; c += 256) sh[c] = gamma[c];
+  __syncthreads();
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wid, nwaves = (int64_t)gridDim.x * 4;
+  const int pc = lane * E;
+  float ag[5][E], ab[5][E];
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+#pragma unroll
+    for (int e = 0; e < E; ++e) ag[p][e] = ab[p][e] = 0.f;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const bf16_t* xr = x + r * COLS + pc;
+    const bf16_t* dr = dy + r * COLS + pc;
+    uint4 xv[5], dv[5], av[HAS_ADD ? 5 : 1];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      xv[p] = *reinterpret_cast<const uint4*>(xr + p * H);
+      dv[p] = *reinterpret_cast<const uint4*>(dr + p * H);
+      if constexpr (HAS_ADD) av[p] = *reinterpret_cast<const uint4*>(dx_add + r * COLS + pc + p * H);
+    }
+    const float mu = mean[r], rs = rstd[r];
+    const bool ok = row_valid[r] != 0;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      float xh[E], d[E];
+      Vec16<T>::unpack(xv[p], xh);
+      Vec16<T>::unpack(dv[p], d);
+      const f32x4_r g0 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc), g1 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc + 4);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float xn = (xh[e] - mu) * rs, gy = d[e] * (e < 4 ? g0[e & 3] : g1[e & 3]);
+        s1 += gy;
+        s2 += gy * xn;
+        ag[p][e] += d[e] * xn;
+        ab[p][e] += d[e];
+      }
+    }
+    const float m1 = wave_sum(s1) * (1.f / COLS), m2 = wave_sum(s2) * (1.f / COLS);
+    float og[5][E];  // dG of the lane's columns, rounded to bf16 (what the two-kernel path stores and reads back)
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      float xh[E], d[E];
+      Vec16<T>::unpack(xv[p], xh);
+      Vec16<T>::unpack(dv[p], d);
+      const f32x4_r g0 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc), g1 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc + 4);
+      float o[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = rs * (d[e] * (e < 4 ? g0[e & 3] : g1[e & 3]) - m1 - (xh[e] - mu) * rs * m2);
+      if constexpr (HAS_ADD) {
+        float w[E];
+        Vec16<T>::unpack(av[p], w);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] += w[e];
+      }
+      Vec16<T>::unpack(make_uint4(f32x2_to_bf16x2(o[0], o[1]), f32x2_to_bf16x2(o[2], o[3]), f32x2_to_bf16x2(o[4], o[5]), f32x2_to_bf16x2(o[6], o[7])),
+                       og[p]);
+    }
+    float ev[E], x1[E], x2[E], oe[E], o1[E], o2[E];
+    Vec16<T>::unpack(xv[0], ev);
+    Vec16<T>::unpack(xv[1], x1);
+    Vec16<T>::unpack(xv[2], x2);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      oe[e] = ok ? og[0][e] + og[3][e] * x1[e] + og[4][e] * x2[e] : 0.f;
+      o1[e] = ok ? og[1][e] + og[3][e] * ev[e] : 0.f;
+      o2[e] = ok ? og[2][e] + og[4][e] * ev[e] : 0.f;
+    }
+    Vec16<T>::store(de + r * H + pc, oe);
+    Vec16<T>::store(da1 + r * H + pc, o1);
+    Vec16<T>::store(da2 + r * H + pc, o2);
+  }
+  // column sums: the four waves add their partials into LDS one after the other, then contiguous atomics
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wid == w) {
+#pragma unroll
+      for (int p = 0; p < 5; ++p)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int c = p * H + pc + e;
+          sh[c] = (w == 0 ? 0.f : sh[c]) + ag[p][e];
+          sh[COLS + c] = (w == 0 ? 0.f : sh[COLS + c]) + ab[p][e];
+        }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * COLS; c += 256) atomicAdd(c < COLS ? d_gamma + c : d_beta + (c - COLS), sh[c]);
+}
+
+extern "C" int case_layernorm_bwd_concat5(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                          const void* dx_add, const void* e, const void* a1, const void* a2, const uint8_t* row_valid, void* de,
+                                          void* da1, void* da2, float* d_gamma, float* d_beta, int64_t rows, int64_t H, int32_t dtype,
+                                          case_stream_t stream) {
+  CASE_REQUIRE(dy && x && gamma && mean && rstd && e && a1 && a2 && row_valid && de && da1 && da2 && d_gamma && d_beta && rows > 0,
+               "case_layernorm_bwd_concat5: bad argument");
+  if (dtype != CASE_BF16 || H != 512)
+    return case_set_error(CASE_E_UNSUPPORTED, "case_layernorm_bwd_concat5: built for bf16 rows of 5 x 512 (run case_layernorm_bwd + case_concat5_bwd)");
+  for (const void* p : {dy, x, dx_add, (const void*)de, (const void*)da1, (const void*)da2})
+    CASE_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "case_layernorm_bwd_concat5: tensors must be 16-byte aligned");
+  (void)e; (void)a1; (void)a2;  // the pieces are read back from the columns of x = G that hold them
+  hipStream_t s = (hipStream_t)stream;
+  const int grid_r = grid_for(rows, 4, 8, 256 * 8);
+  if (dx_add)
+    hipLaunchKernelGGL(ln_bwd_concat5_rows_kernel<true>, dim3(grid_r), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                       (const bf16_t*)dx_add, row_valid, (bf16_t*)de, (bf16_t*)da1, (bf16_t*)da2, d_gamma, d_beta, rows);
+  else
+    hipLaunchKernelGGL(ln_bwd_concat5_rows_kernel<false>, dim3(grid_r), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                       (const bf16_t*)nullptr, row_valid, (bf16_t*)de, (bf16_t*)da1, (bf16_t*)da2, d_gamma, d_beta, rows);
+  return case_check_launch("case_layernorm_bwd_concat5");
 }
 
 extern "C" int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,

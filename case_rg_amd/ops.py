@@ -1482,8 +1482,70 @@ class Concat5Fn(Function):
         return de, d1, d2, None
 
 
-def concat5(e, a1, a2, valid):
-    return Concat5Fn.apply(e, a1, a2, _u8(valid))
+def concat5(e, a1, a2, valid, shape=None):
+    """[e | a1 | a2 | e o a1 | e o a2] with the rows of ``valid`` == 0 zeroed, optionally reshaped.  The result remembers its pieces
+    (``_case_concat5``) so that a LayerNorm applied DIRECTLY to it can run the fused backward (concat5_layer_norm_carry)."""
+    vu = _u8(valid)
+    out = Concat5Fn.apply(e, a1, a2, vu)
+    if shape is not None:
+        out = out.reshape(shape)
+    if out.requires_grad:
+        out._case_concat5 = (e, a1, a2, vu)
+    return out
+
+
+CONCAT5_LN = os.environ.get("CASE_CONCAT5_LN", "1") != "0"  # A/B switch
+
+
+class Concat5LayerNormFn(Function):
+    """(LN(G), G') for G = concat5(e, a1, a2): G' carries the block's residual use of G.  The forward is the ordinary LayerNorm over the
+    concatenation the caller already formed; the BACKWARD goes from (d LN, d G') straight to (d e, d a1, d a2) in one kernel
+    (case_layernorm_bwd_concat5) -- the 5H-wide gradient of G is never written or re-read."""
+
+    @staticmethod
+    def forward(ctx, e, a1, a2, valid_u8, G, gamma, beta, eps):
+        C = G.shape[-1]
+        xa = G.detach().reshape(-1, C)
+        R = xa.shape[0]
+        y = torch.empty_like(xa)
+        mean = torch.empty(R, dtype=torch.float32, device=xa.device)
+        rstd = torch.empty_like(mean)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        A.call("case_layernorm_fwd", _ptr(xa), None, _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), R, C, eps, _code(xa), _stream())
+        ctx.save_for_backward(xa, g, mean, rstd, valid_u8)
+        ctx.shapes = (G.shape, e.shape)
+        return y.view(G.shape), G.detach().view_as(G)
+
+    @staticmethod
+    def backward(ctx, dy, d_carry):
+        xa, g, mean, rstd, valid_u8 = ctx.saved_tensors
+        gshape, eshape = ctx.shapes
+        R, C = xa.shape
+        H = C // 5
+        dy2 = dy.reshape(R, C)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        extra = None
+        if d_carry is not None:
+            extra = d_carry.reshape(R, C).to(xa.dtype)
+            extra = extra if extra.is_contiguous() else extra.contiguous()
+        de, d1, d2 = (torch.empty(R, H, dtype=xa.dtype, device=xa.device) for _ in range(3))
+        dg, db = _zeros_like_shapes(xa.device, (C,), (C,))
+        A.call("case_layernorm_bwd_concat5", _ptr(dy2), _ptr(xa), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(extra), _ptr(xa), _ptr(xa), _ptr(xa),
+               _ptr(valid_u8), _ptr(de), _ptr(d1), _ptr(d2), _ptr(dg), _ptr(db), R, H, _code(xa), _stream())
+        return de.view(eshape), d1.view(eshape), d2.view(eshape), None, None, dg, db, None
+
+
+def concat5_layer_norm_carry(G, gamma, beta, eps):
+    """ops.layer_norm_carry(G, ...) for a G that ops.concat5 made (it carries its pieces as ``_case_concat5``), with the fused backward;
+    None when G is not such a tensor or the kernel does not take the shape."""
+    src = getattr(G, "_case_concat5", None)
+    if (src is None or not CONCAT5_LN or G.dtype != torch.bfloat16 or G.shape[-1] != 2560 or not G.is_contiguous()
+            or not (torch.is_grad_enabled() and G.requires_grad)):
+        return None
+    e, a1, a2, valid_u8 = src
+    # G enters DETACHED: the gradient goes to the pieces directly.  (As a differentiable input with a None gradient, autograd still ran the
+    # concatenation's own backward on a materialised 5H-wide zero tensor.)
+    return Concat5LayerNormFn.apply(e, a1, a2, valid_u8, G.detach(), gamma, beta, eps)
 
 
 class MaxOverPFn(Function):

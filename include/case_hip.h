@@ -189,6 +189,14 @@ int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const floa
 int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                                void* dx_dropped, float* d_gamma, float* d_beta, int64_t rows, int64_t cols, float p, uint64_t seed,
                                uint64_t offset, int32_t dtype, case_stream_t stream);
+/* The backward of LN(G), G = concat5(E, A1, A2) = [E | A1 | A2 | E o A1 | E o A2] with padded rows zeroed (common/Interaction.py:65-72 feeding
+ * common/TransformerBlock.py:25), fused with the backward of the concatenation: dE, dA1, dA2 [rows, H] come out directly, dG (5H wide)
+ * is never written.  x = G as the forward wrote it; dx_add (nullable, [rows, 5H]) a second gradient of G (its residual use, block :27).
+ * dG is rounded to bf16 before the products, as the two-kernel path (case_layernorm_bwd + case_concat5_bwd) stores it.  bf16, H = 512
+ * only; CASE_E_UNSUPPORTED otherwise. */
+int case_layernorm_bwd_concat5(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dx_add,
+                               const void* e, const void* a1, const void* a2, const uint8_t* row_valid, void* de, void* da1, void* da2,
+                               float* d_gamma, float* d_beta, int64_t rows, int64_t H, int32_t dtype, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4/K5/K6 (softmax stage) and the masked softmaxes of K7/K8/K10/K11

@@ -797,6 +797,58 @@ def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_
                g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols - 8, p, seed, off, code, 0)
 
 
+def test_concatenation_backward_inside_the_layernorm_backward_matches_the_two_kernels():
+    """case_layernorm_bwd_concat5 (ops.concat5_layer_norm_carry): Interaction -> first TransformerBlock at H = 512 in bf16 -- the gradients
+    of the encodings and of every parameter equal those of the separate LayerNorm / concat5 backward kernels (dG rounded to bf16 in both),
+    the fused kernel is the one launched, padded rows get zero gradients, forward values are identical."""
+    import case_rg_amd
+    from case_rg_amd import _abi
+    from case_rg_amd.utils import fill_params
+    ops = _ops()
+    ns = case_rg_amd.namespace()
+    case_rg_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        H, B, P, Lp, Lq = 512, 2, 3, 72, 24
+        inter = fill_params(ns.Interaction(H), 5).to(DEV)
+        block = fill_params(ns.TransformerBlock(8, 5 * H, H), 6).to(DEV).train()
+        eq0, ep0 = _rand(B, 1, Lq, H, dt=torch.bfloat16, seed=1), _rand(B, P, Lp, H, dt=torch.bfloat16, seed=2)
+        qm = torch.ones(B, 1, Lq, dtype=torch.bool, device=DEV)
+        pm = torch.ones(B, P, Lp, dtype=torch.bool, device=DEV)
+        pm[0, 1, 50:] = False
+        pm[1, 2, 1:] = False
+        gout = _rand(B, P, Lp, H, dt=torch.bfloat16, seed=3)
+        res = {}
+        for fused in (True, False):
+            ops.CONCAT5_LN = fused
+            eq, ep = eq0.clone().requires_grad_(True), ep0.clone().requires_grad_(True)
+            for p_ in list(inter.parameters()) + list(block.parameters()):
+                p_.grad = None
+            calls = {}
+            raw = _abi.call
+
+            def counting(name, *a):
+                calls[name] = calls.get(name, 0) + 1
+                return raw(name, *a)
+
+            _abi.call = counting
+            try:
+                _, g_qp = inter(eq, ep, qm, pm)
+                y = block(g_qp, pm)
+                y.backward(gout)
+            finally:
+                _abi.call = raw
+            assert calls.get("case_layernorm_bwd_concat5", 0) == (1 if fused else 0)
+            # the query-side concatenation (behind max_over_p) keeps its own backward; the passage side's is inside the fused kernel
+            assert calls.get("case_concat5_bwd", 0) == (1 if fused else 2)
+            res[fused] = [y.detach(), eq.grad, ep.grad] + [p_.grad for p_ in list(inter.parameters()) + list(block.parameters())]
+        assert torch.equal(res[True][0], res[False][0])
+        for a, b in zip(res[True][1:], res[False][1:]):
+            _close(a, b, 4e-3, "gradient through the fused concatenation backward")
+    finally:
+        ops.CONCAT5_LN = True
+        case_rg_amd.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize("which", ["linear", "ffn"])
 def test_layernorm_as_the_tail_of_linear_and_ffn_equals_the_separate_ops(which):
     """ops.linear(ln=...) / ops.ffn(ln=...): identical forward, and gradients equal to the composition with ops.layer_norm (the backward
