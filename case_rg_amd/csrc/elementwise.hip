@@ -476,6 +476,71 @@ __global__ void concat5_bwd_kernel(const T* __restrict__ d_out, const T* __restr
   }
 }
 
+// 16-byte forms of the two kernels above (H a multiple of the vector width, aligned tensors): the scalar forms move 2 bytes per lane and
+// instruction and ran at 2.5 TB/s on the [122 880, 5 x 512] concatenation
+template <typename T>
+__global__ void concat5_fwd_vec_kernel(const T* __restrict__ e, const T* __restrict__ a1, const T* __restrict__ a2,
+                                       const uint8_t* __restrict__ valid, T* __restrict__ out, int64_t rows, int64_t H) {
+  constexpr int E = Vec16<T>::N;
+  const int64_t hv = H / E, n = rows * hv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / hv, c = (i - r * hv) * E;
+    float ev[E], x1[E], x2[E], p1[E], p2[E];
+    Vec16<T>::load(e + r * H + c, ev);
+    Vec16<T>::load(a1 + r * H + c, x1);
+    Vec16<T>::load(a2 + r * H + c, x2);
+    const bool ok = valid[r];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if (!ok) ev[k] = x1[k] = x2[k] = 0.f;
+      p1[k] = ev[k] * x1[k];
+      p2[k] = ev[k] * x2[k];
+    }
+    T* o = out + r * 5 * H + c;
+    Vec16<T>::store(o, ev);
+    Vec16<T>::store(o + H, x1);
+    Vec16<T>::store(o + 2 * H, x2);
+    Vec16<T>::store(o + 3 * H, p1);
+    Vec16<T>::store(o + 4 * H, p2);
+  }
+}
+
+template <typename T>
+__global__ void concat5_bwd_vec_kernel(const T* __restrict__ d_out, const T* __restrict__ e, const T* __restrict__ a1,
+                                       const T* __restrict__ a2, const uint8_t* __restrict__ valid, T* __restrict__ de,
+                                       T* __restrict__ da1, T* __restrict__ da2, int64_t rows, int64_t H) {
+  constexpr int E = Vec16<T>::N;
+  const int64_t hv = H / E, n = rows * hv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / hv, c = (i - r * hv) * E;
+    float ge[E], g1[E], g2[E];
+    if (valid[r]) {
+      const T* g = d_out + r * 5 * H + c;
+      float ev[E], x1[E], x2[E], g3[E], g4[E];
+      Vec16<T>::load(e + r * H + c, ev);
+      Vec16<T>::load(a1 + r * H + c, x1);
+      Vec16<T>::load(a2 + r * H + c, x2);
+      Vec16<T>::load(g, ge);
+      Vec16<T>::load(g + H, g1);
+      Vec16<T>::load(g + 2 * H, g2);
+      Vec16<T>::load(g + 3 * H, g3);
+      Vec16<T>::load(g + 4 * H, g4);
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        ge[k] = ge[k] + g3[k] * x1[k] + g4[k] * x2[k];
+        g1[k] = g1[k] + g3[k] * ev[k];
+        g2[k] = g2[k] + g4[k] * ev[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < E; ++k) ge[k] = g1[k] = g2[k] = 0.f;
+    }
+    Vec16<T>::store(de + r * H + c, ge);
+    Vec16<T>::store(da1 + r * H + c, g1);
+    Vec16<T>::store(da2 + r * H + c, g2);
+  }
+}
+
 template <typename T>
 __global__ void max_over_p_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int32_t* __restrict__ arg, int64_t B,
                                       int64_t P, int64_t inner) {
@@ -701,6 +766,9 @@ extern "C" int case_highway_gate_bwd(const void* dy, const void* gnl, void* d_gn
 extern "C" int case_concat5_fwd(const void* e, const void* a1, const void* a2, const uint8_t* row_valid, void* out,
                                 int64_t rows, int64_t H, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(e && a1 && a2 && row_valid && out && rows > 0 && H > 0, "case_concat5_fwd: bad argument");
+  if (H % (dtype == CASE_BF16 ? 8 : 4) == 0 && al16(e) && al16(a1) && al16(a2) && al16(out))
+    EW_DISPATCH("case_concat5_fwd", rows * H / (dtype == CASE_BF16 ? 8 : 4), concat5_fwd_vec_kernel, (const T*)e, (const T*)a1, (const T*)a2, row_valid,
+                (T*)out, rows, H);
   EW_DISPATCH("case_concat5_fwd", rows * H, concat5_fwd_kernel, (const T*)e, (const T*)a1, (const T*)a2, row_valid, (T*)out,
               rows, H);
 }
@@ -709,6 +777,9 @@ extern "C" int case_concat5_bwd(const void* d_out, const void* e, const void* a1
                                 const uint8_t* row_valid, void* de, void* da1, void* da2, int64_t rows, int64_t H,
                                 int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(d_out && e && a1 && a2 && row_valid && de && da1 && da2 && rows > 0 && H > 0, "case_concat5_bwd: bad argument");
+  if (H % (dtype == CASE_BF16 ? 8 : 4) == 0 && al16(d_out) && al16(e) && al16(a1) && al16(a2) && al16(de) && al16(da1) && al16(da2))
+    EW_DISPATCH("case_concat5_bwd", rows * H / (dtype == CASE_BF16 ? 8 : 4), concat5_bwd_vec_kernel, (const T*)d_out, (const T*)e, (const T*)a1,
+                (const T*)a2, row_valid, (T*)de, (T*)da1, (T*)da2, rows, H);
   EW_DISPATCH("case_concat5_bwd", rows * H, concat5_bwd_kernel, (const T*)d_out, (const T*)e, (const T*)a1, (const T*)a2,
               row_valid, (T*)de, (T*)da1, (T*)da2, rows, H);
 }
