@@ -708,8 +708,23 @@ def case_cfg5_case_train(ns, dev):
     return rec
 
 
+def case_cfg5_masque_train(ns, dev):
+    """Masque at the cfg 5 geometry (d_model 768: head_dim 96 / 480, Lp 512; one query, two passages) -- the multi-passage reader
+    of BASELINE cfg 3 at the long-context width of cfg 5."""
+    v2i, i2v = make_vocab(PROD_V)
+    m = _mod(ns.Masque(40, i2v, v2i, 768), 241, dev)
+    b = synth_batch(1, 2, 512, 64, 40, PROD_V, seed=242, model="masque", filler_passage=False)
+    b = {k: v.to(dev) for k, v in b.items()}
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_rg": losses[1].reshape(1)})
+    rec.update(_model_grads(m, losses, MASQUE_GRAD_NAMES, strided=True))
+    return rec
+
+
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
-PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory", "cfg5_case_train")
+PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory", "cfg5_case_train",
+              "cfg5_masque_train")
 PROD_TEST_CASES = ("prod_case_test", "prod_masque_test")  # greedy decoding at production geometry
 PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too

@@ -26,7 +26,12 @@ def test_oracle_matches_reference_fixture(name):
         # of magnitude 30 is 1e-4 on the probability; ids, inputs and the rank logits keep the tight bar
         check_case(name, rec, rtol=2e-5, atol=2e-6, override={"margin": (3e-4, 2e-6), "top1_prob": (3e-4, 2e-6)})
         return
-    check_case(name, rec, rtol=2e-5, atol=2e-6, grad_rtol=1e-4, grad_atol=1e-5)
+    override = None
+    if name == "cfg5_masque_train":
+        # the rank-1 Interaction weight: its gradient sums Lp x Lq x H = 25 M products per element, which the reference forms through its
+        # [P, Lp, Lq, 3H] tensor and the oracle through two small matrix products -- f32 summation-order noise of 1.8e-5 on a 7.6e-2 tensor
+        override = {"gslice_passage_selection.interaction.dual_att_linear.weight": (3e-4, 2e-5)}
+    check_case(name, rec, rtol=2e-5, atol=2e-6, grad_rtol=1e-4, grad_atol=1e-5, override=override)
 
 
 def test_state_dict_schema_matches_reference_counts():

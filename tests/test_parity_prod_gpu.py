@@ -40,12 +40,19 @@ MODES = {
 BF16_BARS = {"prod_case_train": (2e-2, {"bf16_auto": 0.11, "bf16_large_fused": 0.13, "bf16_small_unfused": 0.095}),
              "prod_masque_train": (2e-2, {"bf16_auto": 0.115, "bf16_large_fused": 0.185, "bf16_small_unfused": 0.145}),
              "cfg5_case_train": (2e-2, {"bf16_auto": 0.15, "bf16_large_fused": 0.2, "bf16_small_unfused": 0.15}),
+             "cfg5_masque_train": (2e-2, {"bf16_auto": 0.15, "bf16_large_fused": 0.2, "bf16_small_unfused": 0.15}),
              "cfg5_block_5h": (1.5e-2, 0.135), "cfg5_block_h": (1.5e-2, 0.16),           # one ReLU block (measured 0.088 / 0.106)
              "cfg5_dec_layer_long_memory": (2e-2, 0.02),                                # GELU only
              "prod_enc_layer": (1.5e-2, None), "prod_block_5h": (1.5e-2, None)}
 
 
-HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "cfg5_case_train": (96, 480), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
+# fp32 entries above the 1e-3 bar, each with its reason.  The rank-1 Interaction weight at H 768: every element of its gradient is a sum of
+# Lp x Lq x P = 65 k signed products per feature with heavy cancellation (|gradient| <= 0.076 from terms of order 1); the reference adds them
+# through its [P, Lp, Lq, 3H] tensor, the CPU oracle through two matrix products (1.8e-5 away: tests/test_oracle_vs_golden.py), the MFMA path
+# in K order inside each accumulator (2.2e-3 of the slice's scale on its worst element; the tensor's norm agrees to 3.0e-4).
+FP32_OVERRIDES = {("cfg5_masque_train", "gslice_passage_selection.interaction.dual_att_linear.weight"): 4e-3}
+
+HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "cfg5_case_train": (96, 480), "cfg5_masque_train": (96, 480), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
              "cfg5_dec_layer_long_memory": (96,), "prod_enc_layer": (64,), "prod_block_5h": (320,)}
 
 
@@ -101,6 +108,8 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
             continue
         is_grad = k.startswith("g")
         tol = tol_grad if is_grad else tol_out
+        if mode == "fp32":
+            tol = FP32_OVERRIDES.get((name, k), tol)
         rel, l2 = scaled_error("%s/%s" % (name, k), got, want), l2_error(got, want)
         record_error(name, mode, k, rel, tol, l2)
         measured = l2 if (is_grad and mode != "fp32" and not k.startswith("gnorm")) else rel
