@@ -498,15 +498,15 @@ struct BwdOut {  // bf16 gradient slices, addressed like q / k / v
 };
 
 // ---- dQ: stationary queries (lane = query); streams K (row + transposed images) and V (row image) -----------------
-template <int D, int NS, int NQ, int TS, int MINW>
-__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaArgs a, const BwdOut g) {
+template <int D, int NS, int NQ, int TS>
+__device__ __forceinline__ void fa_bwd_dq_body(const FaArgs& a, const BwdOut& g, const int bid) {
   constexpr int NT = 64 * NS * NQ, DH = D / NS, KSW = DH / 16, OB = DH / 32, KT = TS / 32;
   static_assert(NS == 1 || KT == 1, "split head dims exchange one 32-key tile per barrier");
   constexpr int RS = Geo<D>::ROW, TR = Geo<D>::TRS;
   constexpr int KR = 0, KTI = TS * RS, VR = KTI + TS * TR, XB = VR + TS * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xbuf = reinterpret_cast<float*>(smem + XB);
-  const int pid = xcd_remap(blockIdx.x, a.nblk);
+  const int pid = xcd_remap(bid, a.nblk);
   const int qt = pid % a.tiles, head = (pid / a.tiles) % a.heads, n = pid / (a.tiles * a.heads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int qb = wave / NS, split = wave % NS;
@@ -597,9 +597,14 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaA
   if (qi < a.Lq) store_transposed<DH>(acc, g.dq + (int64_t)n * a.sq + (int64_t)qi * a.ldq + head * D + split * DH, half, a.scale);
 }
 
+template <int D, int NS, int NQ, int TS, int MINW>
+__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dq_kernel(const FaArgs a, const BwdOut g) {
+  fa_bwd_dq_body<D, NS, NQ, TS>(a, g, (int)blockIdx.x);
+}
+
 // ---- dK / dV: stationary keys (lane = key); streams Q and dO.  WHAT: 3 = both (NS = 1), 1 = dK only, 2 = dV only -------
-template <int D, int NS, int NQ, int TS, int MINW, int WHAT>
-__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const FaArgs a, const BwdOut g) {
+template <int D, int NS, int NQ, int TS, int WHAT>
+__device__ __forceinline__ void fa_bwd_dkv_body(const FaArgs& a, const BwdOut& g, const int bid) {
   constexpr bool DO_K = (WHAT & 1) != 0, DO_V = (WHAT & 2) != 0;
   constexpr int NT = 64 * NS * NQ, DH = D / NS, KSW = DH / 16, OB = DH / 32, KT = TS / 32;
   static_assert(NS == 1 || KT == 1, "split head dims exchange one 32-query tile per barrier");
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
   float* del_s = lse_s + TS;
   uint32_t* rk_s = reinterpret_cast<uint32_t*>(del_s + TS);
   float* xbuf = reinterpret_cast<float*>(smem + XB);
-  const int pid = xcd_remap(blockIdx.x, a.nblk);
+  const int pid = xcd_remap(bid, a.nblk);
   const int ktile = pid % a.tiles, head = (pid / a.tiles) % a.heads, n = pid / (a.tiles * a.heads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int kblk = wave / NS, split = wave % NS;
@@ -734,6 +739,20 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const Fa
   }
 }
 
+template <int D, int NS, int NQ, int TS, int MINW, int WHAT>
+__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_dkv_kernel(const FaArgs a, const BwdOut g) {
+  fa_bwd_dkv_body<D, NS, NQ, TS, WHAT>(a, g, (int)blockIdx.x);
+}
+
+// dQ and dK / dV in ONE launch (head dims that fit one wave: NS = 1): the first nblk workgroups run the query-stationary body, the rest the
+// key-stationary one.  The two kernels are independent; launched one after the other, the short grid of one (a cross-attention's dQ: one
+// workgroup per CU looping over 3840 keys, 110 us) and the tail of the other (dK / dV: 139 us) each leave most of the chip idle.
+template <int D, int NS, int NQ, int TS, int MINW>
+__global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_bwd_both_kernel(const FaArgs a_dq, const FaArgs a_dkv, const BwdOut g) {
+  if ((int)blockIdx.x < a_dq.nblk) fa_bwd_dq_body<D, NS, NQ, TS>(a_dq, g, (int)blockIdx.x);
+  else fa_bwd_dkv_body<D, NS, NQ, TS, 3>(a_dkv, g, (int)blockIdx.x - a_dq.nblk);
+}
+
 // ---- launch helpers ---------------------------------------------------------------------------------------------------
 template <typename KernelT>
 void set_lds(KernelT kernel, size_t bytes) {
@@ -810,10 +829,25 @@ int launch_bwd(FaArgs a, const BwdOut& g, const bf16_t* out, float* delta, hipSt
       set_lds(kdkv, lds_dkv);
       attr = true;
     }
-    hipLaunchKernelGGL(kdq, dim3(a.nblk), dim3(NT), lds_dq, s, a, g);
-    a.tiles = (a.Lk + 32 * NQ - 1) / (32 * NQ);
-    a.nblk = a.tiles * a.heads * a.N;
-    hipLaunchKernelGGL(kdkv, dim3(a.nblk), dim3(NT), lds_dkv, s, a, g);
+    static const bool merged = [] {  // CASE_ATTN_BWD_MERGED=0: two launches (A/B measurements)
+      const char* e = getenv("CASE_ATTN_BWD_MERGED");
+      return !(e && e[0] == '0');
+    }();
+    FaArgs b = a;
+    b.tiles = (a.Lk + 32 * NQ - 1) / (32 * NQ);
+    b.nblk = b.tiles * a.heads * a.N;
+    if (merged && (int64_t)a.nblk + b.nblk < (1ll << 31)) {
+      auto kboth = &fa_bwd_both_kernel<D, NS, NQ, TS, P::MINW>;
+      static bool attr2 = false;
+      if (!attr2) {
+        set_lds(kboth, lds_dkv > lds_dq ? lds_dkv : lds_dq);
+        attr2 = true;
+      }
+      hipLaunchKernelGGL(kboth, dim3(a.nblk + b.nblk), dim3(NT), lds_dkv > lds_dq ? lds_dkv : lds_dq, s, a, b, g);
+    } else {
+      hipLaunchKernelGGL(kdq, dim3(a.nblk), dim3(NT), lds_dq, s, a, g);
+      hipLaunchKernelGGL(kdkv, dim3(b.nblk), dim3(NT), lds_dkv, s, b, g);
+    }
   } else {
     const size_t lds_dk = (size_t)TS * (2 * RS + TR) + 3 * TS * 4 + xb;
     const size_t lds_dv = (size_t)TS * (RS + TR) + 3 * TS * 4 + xb;
