@@ -587,7 +587,7 @@ def main():
                                 "bucket_mb": round(max(b["flat"].numel() for b in trainer.sync.buckets) * 4 / 2 ** 20, 1),
                                 "gradient_mb": round(sum(b["flat"].numel() for b in trainer.sync.buckets) * 4 / 2 ** 20, 1),
                                 "wire_dtype": "bf16" if trainer.sync.comm_dtype is not None else "f32",
-                                "reserved_cus": _A.lib.case_get_reserved_cus()}
+                                "reserved_cus": int(getattr(trainer.sync, "reserved_cus", 0)), "reserved_while": "first all-reduce of the step .. finish()"}
     if a.mode == "cfg5":
         out["metric"] += ", cfg 5 long context"
         if rank == 0 and not a.no_roofline:

@@ -37,9 +37,7 @@ class GradSync:
         if reserve_cus is None:
             reserve_cus = int(os.environ.get("CASE_DP_RESERVE_CUS", "8"))
         self.reserved_cus = reserve_cus if self.params and self.params[0].is_cuda else 0
-        if self.reserved_cus:
-            from . import _abi
-            _abi.call("case_set_reserved_cus", int(self.reserved_cus))
+        self._reserved_now = False  # the reservation is held only while collectives are in flight: first bucket launch .. finish()
         cap = int(bucket_mb * (1 << 20) // 4)
         cur, cur_n = [], 0
         for p in reversed(self.params):
@@ -93,9 +91,18 @@ class GradSync:
             self._launch(b)
             self._next += 1
 
+    def _reserve(self, on):
+        """The persistent kernels leave ``reserved_cus`` compute units to RCCL only between the first all-reduce of a step and the end of
+        finish(): the forward pass (a third of the step, no collective in flight) runs on the whole chip."""
+        if self.reserved_cus and on != self._reserved_now:
+            from . import _abi
+            _abi.call("case_set_reserved_cus", int(self.reserved_cus) if on else 0)
+            self._reserved_now = on
+
     def _launch(self, b):
         """Gather the bucket's gradients into its flat buffer (one multi-tensor copy; gradients that already ARE the bucket
         views, e.g. after an accumulation micro-step, need none) and start the asynchronous all-reduce."""
+        self._reserve(True)
         src, dst = [], []
         for (p, off, n), view in zip(b["items"], b["views"]):
             if p.grad is None:
@@ -137,6 +144,7 @@ class GradSync:
                 p.grad = view
             b["work"], b["pending"] = None, len(b["items"])
         self._next = 0
+        self._reserve(False)
 
     def exposed_ms(self, last=None):
         """Mean time per step the compute stream waited in finish() (synchronises on the recorded events)."""

@@ -41,13 +41,22 @@ def main():
         assert trainer.sync is not None and trainer.sync.active and len(trainer.sync.buckets) >= 1
         opt = FusedAdam(model.parameters(), lr=1e-3)
         losses = []
+        seen = []  # the library's reservation right behind every bucket launch (collectives in flight)
+        launch = trainer.sync._launch
+
+        def watched(b):
+            launch(b)
+            seen.append(_abi.lib.case_get_reserved_cus())
+
+        trainer.sync._launch = watched
         for step in range(3):
             b = {k: v.cuda() for k, v in shard(step, rank).items()}
             losses.append(trainer.train_batch(0, b, "train", opt))
         torch.cuda.synchronize()
         torch.save({"params": {n: p.detach().cpu() for n, p in model.named_parameters()}, "losses": losses,
                     "buckets": len(trainer.sync.buckets), "exposed_ms": trainer.sync.exposed_ms(),
-                    "reserved_cus": _abi.lib.case_get_reserved_cus(),
+                    "reserved_cus": trainer.sync.reserved_cus, "reserved_during_backward": seen,
+                    "reserved_after_step": _abi.lib.case_get_reserved_cus(),
                     "ema": {n: t.detach().cpu() for n, t in trainer.ema.shadow.items()}}, os.path.join(out, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()

@@ -36,6 +36,8 @@ def test_two_ranks_of_the_hip_model_stay_bit_identical_and_match_one_process(tmp
         assert p.returncode == 0, o[-2000:]
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["buckets"] == r1["buckets"] >= 1 and r0["reserved_cus"] == 8, "GradSync reserves one CU per XCD for the collectives by default"
+    # ... and holds the reservation only while collectives are in flight: seen by a gradient hook late in backward, released by finish()
+    assert r0["reserved_during_backward"] and all(v == 8 for v in r0["reserved_during_backward"]) and r0["reserved_after_step"] == 0
     for n in r0["params"]:
         assert torch.equal(r0["params"][n], r1["params"][n]), "ranks drifted apart on " + n
         assert torch.equal(r0["ema"][n], r1["ema"][n]), "EMA shadows drifted apart on " + n
