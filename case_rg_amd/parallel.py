@@ -38,6 +38,8 @@ class GradSync:
             reserve_cus = int(os.environ.get("CASE_DP_RESERVE_CUS", "8"))
         self.reserved_cus = reserve_cus if self.params and self.params[0].is_cuda else 0
         self._reserved_now = False  # the reservation is held only while collectives are in flight: first bucket launch .. finish()
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo (the CPU tests, the shared-GPU rehearsal) sums and finish() divides
+        self._avg_in_collective = dist.get_backend(process_group) == "nccl"
         cap = int(bucket_mb * (1 << 20) // 4)
         cur, cur_n = [], 0
         for p in reversed(self.params):
@@ -112,13 +114,14 @@ class GradSync:
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
         if self.comm_dtype is not None:
             if b.get("wire") is None:
                 b["wire"] = torch.empty(b["flat"].numel(), dtype=self.comm_dtype, device=b["flat"].device)
             b["wire"].copy_(b["flat"])
-            b["work"] = dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b["work"] = dist.all_reduce(b["wire"], op=op, group=self.group, async_op=True)
         else:
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
     def finish(self):
         """Flush the buckets whose hooks did not all fire (zeros stand in for the missing gradients), wait, average, and make
@@ -139,7 +142,8 @@ class GradSync:
         for b in self.buckets:
             if self.comm_dtype is not None:
                 b["flat"].copy_(b["wire"])
-            b["flat"].div_(self.world)
+            if not self._avg_in_collective:
+                b["flat"].div_(self.world)
             for (p, _, _), view in zip(b["items"], b["views"]):
                 p.grad = view
             b["work"], b["pending"] = None, len(b["items"])
