@@ -215,3 +215,33 @@ def test_resident_kernels_without_a_key_mask():
     assert _rel(o, ref_o) < 6e-3
     for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
         assert _rel(qkv.grad.float()[..., sl], ref[..., sl]) < 1.2e-2, name
+
+
+def test_resident_kernels_are_bit_reproducible_across_launches():
+    """K18 / K19 have no atomics and a static DMA schedule: the same inputs must give the same bits, launch after launch, with other
+    work in between (a race between a DMA and its consumer would show as a rare difference) -- 24 rounds on fresh inputs, dropout on."""
+    from case_rg_amd import config
+    ops = _ops()
+    N, h, L, d = 36, 8, 384, 64  # 288 items on 256 persistent workgroups: item boundaries inside a workgroup
+    E = h * d
+    config.set_dropout(True)
+    try:
+        for rnd in range(24):
+            g0 = torch.Generator().manual_seed(1000 + rnd)
+            base = (torch.randn(N, L, 3 * E, generator=g0) * 0.7).to(DEV).to(torch.bfloat16)
+            g = torch.randn(N, L, E, generator=g0).to(DEV).to(torch.bfloat16)
+            valid = torch.ones(N, L, dtype=torch.bool, device=DEV)
+            valid[rnd % N, 100 + 4 * rnd:] = False
+            outs = []
+            for rep in range(2):
+                config.manual_seed(77 + rnd)
+                x = base.clone().requires_grad_()
+                o = ops.attention(x, x, x, 0, E, 2 * E, h, d, key_valid=valid, p_drop=0.1)
+                if rep == 0:  # unrelated work between the two launches
+                    torch.mm(base[0].float(), base[1].float().t())
+                o.backward(g)
+                outs.append((o.detach().clone(), x.grad.clone()))
+            assert torch.equal(outs[0][0], outs[1][0]), "forward differs between two launches (round %d)" % rnd
+            assert torch.equal(outs[0][1], outs[1][1]), "backward differs between two launches (round %d)" % rnd
+    finally:
+        config.set_dropout(False)
