@@ -2,8 +2,10 @@
 
     x = LN1(x); x += drop(SelfAttn(x; causal, key pad)); x = LN2(x); x += drop(CrossAttn(x, memory; key pad));
     x = LN3(x); x += drop(W2 drop(act(W1 x)))
-The layers return ``(x, None, None)``: the head-averaged attention weights of the reference are discarded
-by every caller on the path and are not materialised here.
+The layers return ``(x, None, None)`` by default: the head-averaged attention weights of the reference are discarded by every
+caller on the path.  Set ``return_attention = True`` on a layer / stack to get them (reference :77-90, :208-218:
+the self-attention and memory-attention weights of the layer, the stack returns its LAST layer's), computed on request by
+MultiheadAttention.averaged_weights.
 """
 import torch
 import torch.nn as nn
@@ -64,9 +66,18 @@ class TransformerDecoderLayer(nn.Module):
             raise NotImplementedError("memory_mask is not used on the CaSE path")
         tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
         mv = None if memory_key_padding_mask is None else ~memory_key_padding_mask
-        y = self.forward_batch_first(tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), tv, mv,
-                                     causal=is_causal_mask(tgt_mask))
-        return y.transpose(0, 1), None, None
+        xb, mb, causal = tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), is_causal_mask(tgt_mask)
+        y = self.forward_batch_first(xb, mb, tv, mv, causal=causal)
+        if not getattr(self, "return_attention", False):
+            return y.transpose(0, 1), None, None
+        # the weights of THIS layer's two attentions, recomputed from its inputs (eval-mode values: no dropout on the probabilities)
+        n1 = ops.layer_norm(xb, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        w_self = self.self_attn.averaged_weights(n1, n1, tv, causal)
+        with torch.no_grad():
+            n2 = ops.layer_norm(self.self_attn.self_attention(n1, tv, causal=causal, residual=n1), self.norm2.weight, self.norm2.bias,
+                                self.norm2.eps)
+        w_mem = self.multihead_attn.averaged_weights(n2, mb, mv, False)
+        return y.transpose(0, 1), w_self, w_mem
 
 
 class GenericTransformerDecoderLayer(nn.Module):
@@ -180,6 +191,18 @@ class TransformerDecoder(nn.Module):
             raise NotImplementedError("memory_mask is not used on the CaSE path")
         tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
         mv = None if memory_key_padding_mask is None else ~memory_key_padding_mask
+        if getattr(self, "return_attention", False):  # the reference's loop: every layer through its own forward, the last layer's weights
+            out, w_self, w_mem = tgt, None, None
+            for layer in self.layers:
+                layer.return_attention = True
+                try:
+                    out, w_self, w_mem = layer(out, memory, tgt_mask=tgt_mask, tgt_key_padding_mask=tgt_key_padding_mask,
+                                               memory_key_padding_mask=memory_key_padding_mask)
+                finally:
+                    layer.return_attention = False
+            if self.norm is not None:
+                out = ops.layer_norm(out, self.norm.weight, self.norm.bias, self.norm.eps)
+            return out, w_self, w_mem
         y = self.forward_batch_first(tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), tv, mv,
                                      causal=is_causal_mask(tgt_mask))
         return y.transpose(0, 1), None, None

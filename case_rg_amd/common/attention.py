@@ -69,20 +69,44 @@ class MultiheadAttention(nn.Module):
                           p_drop=config.drop_p(p_res, self.training), ln=ln)
 
     # -- nn.MultiheadAttention-compatible call (sequence-first) ---------------------------------
-    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
-        """[L, N, E] tensors; ``key_padding_mask`` True = pad.  Returns (out [Lq, N, E], None): the
-        head-averaged weights the reference discards (``[0]``) are not materialised."""
-        if key is not value:
-            raise NotImplementedError("key and value must be the same tensor (all call sites on the CaSE path)")
+    def averaged_weights(self, query, key, key_valid=None, causal=False):
+        """Head-averaged attention probabilities [N, Lq, Lk] of batch-first ``query`` [N, Lq, E] over ``key`` [N, Lk, E] -- what
+        nn.MultiheadAttention returns as its second value (F.multi_head_attention_forward: softmax weights summed over the heads / heads).
+        Computed on request only, by the score GEMM + masked softmax (no dropout: the reference's callers read them in eval mode, if at
+        all -- every call site on the CaSE / Masque path discards them); not differentiable."""
+        E, h, d = self.embed_dim, self.num_heads, self.head_dim
+        with torch.no_grad():
+            q = ops.linear(query, self.in_proj_weight[:E], self.in_proj_bias[:E])
+            k = ops.linear(key, self.in_proj_weight[E:2 * E], self.in_proj_bias[E:2 * E])
+            P, _ = ops.AttentionFn._probabilities(q.contiguous(), k.contiguous(), 0, 0, h, d, ops._u8(key_valid), causal, None, 1.0 / (d ** 0.5))
+            return P.float().mean(dim=1)
+
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=False):
+        """[L, N, E] tensors; ``key_padding_mask`` True = pad.  Returns (out [Lq, N, E], weights): ``weights`` is None unless
+        ``need_weights`` (then the head-averaged probabilities [N, Lq, Lk], see ``averaged_weights``).  ``key`` and ``value`` may be
+        different tensors of the same length (projected with their own rows of the packed in-projection); an ``attn_mask`` must be the
+        square subsequent (causal) mask."""
         valid = None if key_padding_mask is None else ~key_padding_mask
         q = query.transpose(0, 1).contiguous()
-        if query is key:
-            out = self.self_attention(q, valid, causal=is_causal_mask(attn_mask))
-        else:
-            if attn_mask is not None:
-                raise NotImplementedError("memory_mask is not used on the CaSE path")
-            out = self.cross_attention(q, key.transpose(0, 1).contiguous(), valid)
-        return out.transpose(0, 1), None
+        causal = is_causal_mask(attn_mask)
+        if key is value and query is key:
+            out = self.self_attention(q, valid, causal=causal)
+            kb = q
+        elif key is value and not causal:
+            kb = key.transpose(0, 1).contiguous()
+            out = self.cross_attention(q, kb, valid)
+        else:  # the general form: three projections, the attention core on three sources
+            E = self.embed_dim
+            kb, vb = key.transpose(0, 1).contiguous(), value.transpose(0, 1).contiguous()
+            if kb.shape[:2] != vb.shape[:2]:
+                raise RuntimeError("key and value must have the same sequence length and batch size")
+            w, b = self.in_proj_weight, self.in_proj_bias
+            qp, kp, vp = ops.linear(q, w[:E], b[:E]), ops.linear(kb, w[E:2 * E], b[E:2 * E]), ops.linear(vb, w[2 * E:], b[2 * E:])
+            ctx = ops.attention(qp, kp, vp, 0, 0, 0, self.num_heads, self.head_dim, key_valid=valid, causal=causal,
+                                p_drop=config.drop_p(self.dropout, self.training))
+            out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
+        weights = self.averaged_weights(q, kb, valid, causal) if need_weights else None
+        return out.transpose(0, 1), weights
 
 
 def is_causal_mask(mask):

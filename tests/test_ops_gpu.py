@@ -804,6 +804,71 @@ def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_
                g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols - 8, p, seed, off, code, 0)
 
 
+@pytest.mark.parametrize("form", ["self", "cross", "key_is_not_value"])
+def test_multihead_attention_general_call_forms_match_torch(form):
+    """The nn.MultiheadAttention-compatible ``forward`` (sequence-first): output AND head-averaged weights (``need_weights``) against
+    torch.nn.MultiheadAttention itself in eval mode, for self-attention with the causal mask, cross-attention with key padding, and the
+    general form with different key and value tensors (reference call sites: common/TransformerDecoder.py:77-82)."""
+    from case_rg_amd.common.attention import MultiheadAttention
+    _ops()
+    E, h, N, Lq, Lk = 128, 4, 3, 10, 14
+    mha = MultiheadAttention(E, h, dropout=0.1).to(DEV).eval()
+    ref = torch.nn.MultiheadAttention(E, h, dropout=0.1).eval()
+    with torch.no_grad():
+        mha.in_proj_bias.copy_(_rand(3 * E, seed=4) * 0.1)
+        mha.out_proj.bias.copy_(_rand(E, seed=5) * 0.1)
+        ref.in_proj_weight.copy_(mha.in_proj_weight.cpu())
+        ref.in_proj_bias.copy_(mha.in_proj_bias.cpu())
+        ref.out_proj.weight.copy_(mha.out_proj.weight.cpu())
+        ref.out_proj.bias.copy_(mha.out_proj.bias.cpu())
+    q = _rand(Lq, N, E, seed=1)
+    if form == "self":
+        k = v = q
+        pad = torch.zeros(N, Lq, dtype=torch.bool)
+        mask = torch.triu(torch.full((Lq, Lq), float("-inf")), 1)
+    else:
+        k = _rand(Lk, N, E, seed=2)
+        v = k if form == "cross" else _rand(Lk, N, E, seed=3)
+        pad = torch.zeros(N, Lk, dtype=torch.bool)
+        pad[1, 9:] = True
+        mask = None
+    with torch.no_grad():
+        out, w = mha(q, k, v, attn_mask=None if mask is None else mask.to(DEV), key_padding_mask=pad.to(DEV), need_weights=True)
+        out2, w2 = mha(q, k, v, attn_mask=None if mask is None else mask.to(DEV), key_padding_mask=pad.to(DEV))
+        want, ww = ref(q.cpu(), k.cpu(), v.cpu(), attn_mask=mask, key_padding_mask=pad, need_weights=True)
+    assert w2 is None and torch.equal(out, out2)
+    _close(out.cpu(), want, 1e-4, "attention output (%s)" % form)
+    _close(w.cpu(), ww, 1e-4, "head-averaged weights (%s)" % form)
+
+
+def test_decoder_stack_returns_the_last_layers_attention_weights_on_request():
+    """``return_attention = True`` on a TransformerDecoder: (output, self-attention weights, memory-attention weights) of the LAST layer,
+    head-averaged, as the reference returns them (common/TransformerDecoder.py:77-90, :208-218) -- against the f32 oracle; off by
+    default (None, None)."""
+    import case_rg_amd
+    import oracle
+    from case_rg_amd.utils import fill_params
+    _ops()
+    ns = case_rg_amd.namespace()
+    E, h, N, T, S, layers = 128, 4, 3, 9, 21, 2
+    dec = fill_params(ns.TransformerDecoder(ns.TransformerDecoderLayer(E, h, dim_feedforward=E, dropout=0.1, activation="gelu"), layers), 5).to(DEV).eval()
+    ref = fill_params(oracle.TransformerDecoder(oracle.TransformerDecoderLayer(E, h, dim_feedforward=E, dropout=0.1, activation="gelu"), layers), 5).eval()
+    tgt, mem = _rand(T, N, E, seed=1), _rand(S, N, E, seed=2)
+    tpad, mpad = torch.zeros(N, T, dtype=torch.bool), torch.zeros(N, S, dtype=torch.bool)
+    mpad[2, 15:] = True
+    causal = torch.triu(torch.full((T, T), float("-inf")), 1)
+    with torch.no_grad():
+        y0, a0, b0 = dec(tgt, mem, tgt_mask=causal.to(DEV), tgt_key_padding_mask=tpad.to(DEV), memory_key_padding_mask=mpad.to(DEV))
+        dec.return_attention = True
+        y1, a1, b1 = dec(tgt, mem, tgt_mask=causal.to(DEV), tgt_key_padding_mask=tpad.to(DEV), memory_key_padding_mask=mpad.to(DEV))
+        want = ref(tgt.cpu(), mem.cpu(), tgt_mask=causal, tgt_key_padding_mask=tpad, memory_key_padding_mask=mpad)
+    assert a0 is None and b0 is None
+    _close(y1.cpu(), y0.cpu(), 1e-5, "output with and without the weights")
+    _close(y1.cpu(), want[0], 1e-4, "decoder output")
+    _close(a1.cpu(), want[1], 1e-4, "self-attention weights of the last layer")
+    _close(b1.cpu(), want[2], 1e-4, "memory-attention weights of the last layer")
+
+
 def test_concatenation_backward_inside_the_layernorm_backward_matches_the_two_kernels():
     """case_layernorm_bwd_concat5 (ops.concat5_layer_norm_carry): Interaction -> first TransformerBlock at H = 512 in bf16 -- the gradients
     of the encodings and of every parameter equal those of the separate LayerNorm / concat5 backward kernels (dG rounded to bf16 in both),
