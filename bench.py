@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- train tokens/s (query+passage) of the CaSE model on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -67,6 +66,9 @@ def parse():
                          "encoder: the north-star point, TransformerSeqEncoder forward at batch x passages x passage-len; "
                          "cfg5: the long-context training step (d_model 768, 40 passages x 512 tokens, batch 4 per GPU) with the "
                          "HBM roofline of its long-memory cross-attention")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="data parallel: compute units the persistent kernels leave to RCCL while collectives are in flight (default: "
+                         "CASE_DP_RESERVE_CUS or 8); sweep 0 / 8 / 16 and compare data_parallel.allreduce_exposed_ms")
     ap.add_argument("--decode-len", type=int, default=64)
     ap.add_argument("--graph", action="store_true", help="decode: replay the whole greedy pass from one captured hipGraph")
     return ap.parse_args()
@@ -136,20 +138,30 @@ def build(a, device):
     return trainer, opt, sched, batch
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of ``kernel_key`` from the newest committed PMC summary (profiles/*_pmc_traffic.json, made by
-    tools/pmc_traffic.py from two rocprofv3 --pmc passes of this same command); None when there is none."""
+def workload_key(a):
+    """What a committed PMC summary was measured on: a traffic figure is attached only to a run of the SAME workload."""
+    return "%s/b%d/h%d/p%dx%d/enc%d/%s" % (a.model, a.batch, a.hidden, a.passages, a.passage_len, a.enc_layers, a.dtype)
+
+
+def pmc_traffic(kernel_key, workload, pattern="*_pmc_traffic.json"):
+    """ARCHIVED HBM bytes per launch of ``kernel_key``: the newest committed PMC summary (profiles/*_pmc_traffic.json, made by
+    tools/pmc_traffic.py from two rocprofv3 --pmc passes, see tools/r05_pmc.sh) whose ``workload`` equals this run's; files written
+    before round 5 carry no key and were all measured on the default CaSE cfg 2 line.  (None, None) when there is none: a PMC
+    number of another model / batch is never printed beside this run's timings."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as fh:
-            k = json.load(fh)["kernels"].get(kernel_key)
-        return (k["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])) if k else (None, None)
-    except (OSError, ValueError, KeyError):
-        return None, None
+    for path in reversed(sorted(glob.glob(os.path.join(here, "profiles", pattern)))):
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+            if rec.get("workload", "case/b32/h512/p10x384/enc6/bf16") != workload:
+                continue
+            k = rec["kernels"].get(kernel_key)
+            if k:
+                return k["hbm_bytes_per_launch"], "profiles/" + os.path.basename(path)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def roofline_step(a, trainer, opt, sched, batch):
@@ -201,10 +213,10 @@ def roofline_step(a, trainer, opt, sched, batch):
                          % (k[0], k[1], k[2], k[3], k[4], k[5], v[2], v[1], v[0] / v[1] / 1e9))
     key, (flops, secs, n, alg_bytes) = max(fam.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
-    traffic, traffic_src = pmc_traffic(key)
+    traffic, traffic_src = pmc_traffic(key, workload_key(a))
     all_flops, all_secs = sum(v[0] for v in fam.values()), sum(v[1] for v in fam.values())
     return {"bound": "mfma", "kernel": key, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_archived": traffic is not None,
             "algorithmic_bytes_per_launch": round(alg_bytes / n), "launches": n,
             "avg_launch_ms": round(secs / n * 1e3, 4), "flops_per_launch": flops / n,
             "all_gemm_tflops": round(all_flops / all_secs / 1e12, 1), "all_gemm_ms_per_step": round(all_secs * 1e3, 2),
@@ -233,19 +245,12 @@ def roofline_cross_attention(a, device):
         torch.cuda.synchronize()
     secs = e0.elapsed_time(e1) / iters * 1e-3
     nbytes = N * S * 2 * E * 2
-    traffic, traffic_src = None, None  # PMC bytes of the split-KV forward launch alone (tools/cfg5_stream.py under two rocprofv3 passes)
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_cfg5stream_pmc.json")))
-    if files:
-        try:
-            with open(files[-1]) as fh:
-                traffic = json.load(fh)["kernels"]["fa_fwd_kernel"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/" + os.path.basename(files[-1])
-        except (OSError, ValueError, KeyError):
-            pass
+    # ARCHIVED PMC bytes of the split-KV forward launch alone (tools/cfg5_stream.py under two rocprofv3 passes: tools/r05_pmc.sh)
+    traffic, traffic_src = pmc_traffic("fa_fwd_kernel", workload_key(a), "*_cfg5stream_pmc.json")
     return {"bound": "hbm", "kernel": "fa_fwd_kernel<96, split-KV> + fa_combine_kernel<96> (decoder cross-attention, S = %d)" % S,
             "achieved": round(nbytes / secs / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / secs / 8e12, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(secs * 1e3, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_archived": traffic is not None, "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_ms": round(secs * 1e3, 4),
             "launches_per_step": "8 forward (2 stacks x 4 layers; the query-memory stack has S = %d)" % a.query_len}
 
 
@@ -535,7 +540,14 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    if a.reserve_cus is not None:
+        os.environ["CASE_DP_RESERVE_CUS"] = str(a.reserve_cus)
     trainer, opt, sched, batch = build(a, device)
+    ranks_seen = None
+    if dist.is_initialized():  # self-certification of the collective: a real 1-element all-reduce(SUM) of ones over the process group
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
 
     def step():
         return trainer.train_batch(0, dict(batch), "train", opt, sched)
@@ -578,6 +590,7 @@ def main():
         "step_mfma_frac": round(3 * fwd / (elapsed / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "last_losses": [round(x, 4) for x in losses],
         "world_size": dist.get_world_size() if dist.is_initialized() else 1, "rank_ms_per_step": rank_ms,
+        "rccl_ranks_seen": ranks_seen, "collective_backend": dist.get_backend() if dist.is_initialized() else None,
     }
     if trainer.sync is not None and trainer.sync.active:
         # how long the compute stream stood still in GradSync.finish() per step (HIP events around the waits, this rank; the timed

@@ -58,6 +58,14 @@ class CumulativeTrainer(object):
         self._loss_host = None
 
     def train_batch(self, epoch, data, method, optimizer, scheduler=None):
+        try:
+            return self._train_batch(epoch, data, method, optimizer, scheduler)
+        except BaseException:
+            if self.sync is not None:  # the step died between backward and finish(): release what GradSync holds (reserved CUs, buckets)
+                self.sync.abort()
+            raise
+
+    def _train_batch(self, epoch, data, method, optimizer, scheduler=None):
         self.accumulation_count += 1
         boundary = self.accumulation_count % self.accumulation_steps == 0
         if self.sync is not None:

@@ -165,7 +165,7 @@ extern "C" int case_gemm_dw_bias(const CaseGemmDesc* d, const void* A, const voi
     return case_set_error(CASE_E_UNSUPPORTED, "case_gemm_dw_bias: needs the 256x256 tiling (see case_gemm_tile_for), a k-major A, "
                                               "the bare ATOMIC epilogue and f32 output");
   a.rowsum = d_bias;
-  return gemm_t8w::launch<float, 1>(a, d->epilogue, d->a_kmajor, d->b_kmajor, device_cus(), (hipStream_t)stream);
+  return gemm_t8w::launch<float, 1>(a, d->epilogue, d->a_kmajor, d->b_kmajor, case_persistent_cus(), (hipStream_t)stream);
 }
 
 namespace {
@@ -218,7 +218,7 @@ extern "C" int case_gemm_dw_slabs(const CaseGemmDesc* d, const void* A, const vo
   a.slabs = reinterpret_cast<float*>(slabs);
   a.slab_stride = d->M * d->N;
   hipStream_t s = (hipStream_t)stream;
-  const int rg = gemm_t8w::launch<float, 2>(a, d->epilogue, d->a_kmajor, d->b_kmajor, device_cus(), s);
+  const int rg = gemm_t8w::launch<float, 2>(a, d->epilogue, d->a_kmajor, d->b_kmajor, case_persistent_cus(), s);
   if (rg) return rg;
   const int64_t quads = d->M * d->N / 4;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.slabs, reinterpret_cast<float*>(C), quads,

@@ -1089,6 +1089,8 @@ extern "C" int case_layernorm_bwd_dropout(const void* dy, const void* x, const f
                                           uint64_t offset, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_dropped && d_gamma && d_beta && rows > 0 && cols > 0 && p > 0.f && p < 1.f,
                "case_layernorm_bwd_dropout: bad argument");
+  // the dual-output kernels draw one 64-bit hash per element PAIR (offset + even index); case_dropout does the same only for even offsets
+  CASE_REQUIRE((offset & 1) == 0, "case_layernorm_bwd_dropout: the RNG offset must be even (the mask is drawn per element pair)");
   const LnDrop dr = {dx_dropped, p, seed, offset};
   hipStream_t s = (hipStream_t)stream;
   bool ok = false;

@@ -32,6 +32,8 @@ class GradSync:
         self.active = dist.is_initialized() and (self.world > 1 or force)
         self.exposed = []  # (start, end) event pairs around finish()'s waits on the compute stream: exposed_ms()
         self.comm_dtype = comm_dtype if comm_dtype is not None else (torch.bfloat16 if os.environ.get("CASE_DP_BF16") == "1" else None)
+        self._reserved_now = False
+        self.reserved_cus = 0
         if not self.active:
             return
         if reserve_cus is None:
@@ -73,7 +75,21 @@ class GradSync:
 
     def no_sync(self, flag=True):
         """Gradient accumulation micro-steps: skip the all-reduce (the reference does not)."""
+        if self.active and self._reserved_now and self._next == 0:
+            self._reserve(False)  # a step that never reached finish() (backward raised) must not leave the chip short of CUs
         self._armed = not flag
+
+    def abort(self):
+        """A step was abandoned between backward and finish() (an exception, an early exit): wait for the collectives already in
+        flight -- every rank launched the same ones --, forget the partial state and hand the reserved CUs back."""
+        if not self.active:
+            return
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+            b["work"], b["pending"] = None, len(b["items"])
+        self._next = 0
+        self._reserve(False)
 
     def _on_grad(self, p):
         if not self._armed:
@@ -126,7 +142,10 @@ class GradSync:
     def finish(self):
         """Flush the buckets whose hooks did not all fire (zeros stand in for the missing gradients), wait, average, and make
         every ``param.grad`` a VIEW of its bucket: the optimizer reads the reduced gradients in place, nothing is copied back."""
-        if not self.active or not self._armed:
+        if not self.active:
+            return
+        if not self._armed:
+            self._reserve(False)
             return
         self._launch_ready(flush=True)
         timed = self.buckets and self.buckets[0]["flat"].is_cuda

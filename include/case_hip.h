@@ -185,7 +185,8 @@ int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const floa
  * 72-75, common/TransformerBlock.py:27-28 -- with TWO outputs: dx (the gradient of the LayerNorm's input = of the residual r) and
  * dx_dropped = mask * dx / (1 - p), the gradient of the Linear's pre-dropout output that its dX / dW GEMMs read.  The mask is case_dropout's
  * (element index row * cols + column behind (seed, offset)) applied to the ROUNDED dx: the same bits as case_layernorm_bwd followed by
- * case_dropout, one tensor pass less.  Rows of k x 64 lanes x 16 bytes (k <= 8), no x2 / dx_add; CASE_E_UNSUPPORTED otherwise. */
+ * case_dropout, one tensor pass less.  Rows of k x 64 lanes x 16 bytes (k <= 8), no x2 / dx_add; CASE_E_UNSUPPORTED otherwise.
+ * `offset` must be EVEN (the mask is drawn per element pair; CASE_E_ARG otherwise -- case_dropout itself accepts odd offsets). */
 int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                                void* dx_dropped, float* d_gamma, float* d_beta, int64_t rows, int64_t cols, float p, uint64_t seed,
                                uint64_t offset, int32_t dtype, case_stream_t stream);

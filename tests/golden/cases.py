@@ -566,6 +566,35 @@ def case_prod_masque_train(ns, dev):
     return rec
 
 
+# The FULL per-item geometry of cfg 2 (VERDICT r4 missing 6): one query x TEN passages x 384, ragged lengths, one filler passage -- the
+# decoder's memory is S = 3840 tokens (split-KV cross-attention forward + merged backward in the bench mode), the query side of the
+# Interaction is the max over ten passages, the copy prior is normalised over 3840 tokens.  The reference's [B P, Lp, Lq, 3H] temporary is
+# 1.5 GB here; ~25 s per model on the build container's CPU.
+def _prod_batch_p10(dev, seed, model):
+    b = synth_batch(1, 10, 384, 64, 40, PROD_V, seed=seed, model=model)
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def case_prod_case_train_p10(ns, dev):
+    m = _prod_model(ns, dev, 251, "case")
+    b = _prod_batch_p10(dev, 252, "case")
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_se": losses[1].reshape(1), "loss_rg": losses[2].reshape(1)})
+    rec.update(_model_grads(m, losses, CASE_GRAD_NAMES, strided=True))
+    return rec
+
+
+def case_prod_masque_train_p10(ns, dev):
+    m = _prod_model(ns, dev, 261, "masque")
+    b = _prod_batch_p10(dev, 262, "masque")
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_rg": losses[1].reshape(1)})
+    rec.update(_model_grads(m, losses, MASQUE_GRAD_NAMES, strided=True))
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------
 # greedy decoding at PRODUCTION geometry (BASELINE cfg 4 shapes per item: H 512, 8 heads of 64, Lp 384, Lq 64, V 30522): the
 # reference's own O(T^2) loop (CaSE/Model.py:91-123, Masque/Model.py:85-117) on two queries x two passages, T = 14 steps.  On
@@ -725,6 +754,6 @@ def case_cfg5_masque_train(ns, dev):
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
 PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory", "cfg5_case_train",
-              "cfg5_masque_train")
+              "cfg5_masque_train", "prod_case_train_p10", "prod_masque_train_p10")
 PROD_TEST_CASES = ("prod_case_test", "prod_masque_test")  # greedy decoding at production geometry
 PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate the golden fixtures by importing the reference itself (build container only).
 
     python tests/golden/gen_golden.py            # writes tests/golden/<case>.npz

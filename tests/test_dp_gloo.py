@@ -68,6 +68,23 @@ def _worker(rank, world, port, out_dir):
         sum(l.mean() for l in losses).backward()
         sync.finish()
         rec["grads_mixed"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        # an abandoned step: backward ran (some collectives are in flight), finish() never did; abort() must leave a clean slate
+        model.zero_grad()
+        sum(l.mean() for l in model(dict(_shard(rank)), method="train")).backward()
+        sync.abort()
+        assert sync._next == 0 and all(b["work"] is None and b["pending"] == len(b["items"]) for b in sync.buckets)
+        model.zero_grad()
+        sum(l.mean() for l in model(dict(_shard(rank)), method="train")).backward()
+        sync.finish()
+        rec["grads_after_abort"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        # the bf16 wire (CASE_DP_BF16 / comm_dtype): gradients rounded once, summed, divided -- a second GradSync on the same model
+        for h in sync._handles:
+            h.remove()
+        wire = GradSync(model, bucket_mb=0.05, comm_dtype=torch.bfloat16)
+        model.zero_grad()
+        sum(l.mean() for l in model(dict(_shard(rank)), method="train")).backward()
+        wire.finish()
+        rec["grads_bf16_wire"] = {n: p.grad.clone() for n, p in model.named_parameters()}
         torch.save(rec, os.path.join(out_dir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -93,3 +110,12 @@ def test_gradsync_world2_gloo(tmp_path):
         g1 = torch.zeros_like(p) if p.grad is None else p.grad
         assert torch.allclose(r0["grads_mixed"][n], 0.5 * (g0[n] + g1), rtol=1e-5, atol=1e-7), "mixed graphs: " + n
         assert torch.equal(r0["grads_mixed"][n], r1["grads_mixed"][n]), "ranks disagree on " + n
+    g1 = _grads(ref, _shard(1))
+    for n in g0:
+        want = 0.5 * (g0[n] + g1[n])
+        assert torch.allclose(r0["grads_after_abort"][n], want, rtol=1e-5, atol=1e-7), "after abort: " + n
+        assert torch.equal(r0["grads_after_abort"][n], r1["grads_after_abort"][n])
+        # bf16 wire: each rank's gradient rounded to bf16 (2^-9 relative), the sum rounded again
+        got = r0["grads_bf16_wire"][n]
+        assert torch.equal(got, r1["grads_bf16_wire"][n]), "bf16 wire: ranks disagree on " + n
+        assert (got - want).abs().max() <= 1.2e-2 * want.abs().max() + 1e-8, "bf16 wire: " + n

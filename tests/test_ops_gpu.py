@@ -464,6 +464,59 @@ def _fused_attention_case(ops, _abi, config, N, h, Lq, Lk, d, causal):
         config.set_dropout(False)
 
 
+@pytest.mark.parametrize("N,ragged", [(32, False), (4, True)])
+def test_decoder_cross_attention_at_the_benchmark_memory_length(N, ragged):
+    """The decoder's cross-attention as bench.py times it (cfg 2: T = 40 queries x 8 heads of 64 over the 10 x 384 = 3840-token memory,
+    common/TransformerDecoder.py:81-82, CaSE/Model.py:57-58): ops._kv_splits sends its forward to case_attention_fwd_splitkv and its
+    backward to the merged dQ | dK / dV launch.  Values AND gradients against an f32 reference on the same bf16 inputs, full batch and
+    a ragged one (keys masked per passage as padded passages are, one item WITHOUT any valid key: exact zeros there)."""
+    from case_rg_amd import _abi
+    ops = _ops()
+    h, Lq, Lk, d = 8, 40, 3840, 64
+    E, dt = h * d, torch.bfloat16
+    valid = torch.ones(N, Lk, dtype=torch.bool, device=DEV)
+    if ragged:
+        lens = torch.tensor([[384, 200, 2, 377, 192, 384, 300, 250, 2, 311]], device=DEV).expand(N, 10).clone()
+        lens[1] = torch.tensor([2, 2, 2, 384, 2, 2, 2, 2, 2, 193], device=DEV)
+        valid = (torch.arange(384, device=DEV)[None, None, :] < lens[:, :, None]).reshape(N, Lk)
+        valid[2] = False  # no key at all
+    qs = _rand(N, Lq, E, dt=dt, seed=1, scale=0.7).requires_grad_()
+    kv = _rand(N, Lk, 2 * E, dt=dt, seed=2, scale=0.7).requires_grad_()
+    seen, raw = [], _abi.call
+
+    def spy(name, *a):
+        if name.startswith("case_attention"):
+            seen.append((name, int(a[0].head_dim), int(a[0].Lk)))
+        return raw(name, *a)
+
+    _abi.call = spy
+    try:
+        assert ops._kv_splits(N, h, Lq, Lk, False) > 1
+        o = ops.attention(qs, kv, kv, 0, 0, E, h, d, key_valid=valid, causal=False)
+        g = _rand(N, Lq, E, dt=dt, seed=3)
+        o.backward(g)
+        torch.cuda.synchronize()
+    finally:
+        _abi.call = raw
+    assert ("case_attention_fwd_splitkv", 64, Lk) in seen, seen
+    assert ("case_attention_bwd", 64, Lk) in seen, seen
+    rq, rkv = qs.detach().float().requires_grad_(), kv.detach().float().requires_grad_()
+    rk, rv = rkv.split(E, dim=-1)
+    rqh, rkh, rvh = [t.reshape(N, -1, h, d).transpose(1, 2) for t in (rq, rk, rv)]
+    sc = (rqh @ rkh.transpose(-1, -2)) / math.sqrt(d)
+    sc = sc.masked_fill(~valid[:, None, None, :], float("-inf"))
+    p = torch.nan_to_num(torch.softmax(sc, -1), nan=0.0)  # a sequence without a valid key: zeros, as the reference's callers mask it
+    ref = (p @ rvh).transpose(1, 2).reshape(N, Lq, E)
+    ref.backward(g.float())
+    _close(o, ref, 2e-2, "cross-attention o")
+    _close(qs.grad, rq.grad, 4e-2, "cross-attention dq")
+    _close(kv.grad, rkv.grad, 4e-2, "cross-attention dkv")
+    if ragged:
+        assert float(o[2].float().abs().max()) == 0.0 and float(qs.grad[2].float().abs().max()) == 0.0
+        assert float(kv.grad[2].float().abs().max()) == 0.0
+        assert float(kv.grad.float().masked_select(~valid[:, :, None]).abs().max()) == 0.0, "gradient on a masked key"
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_k_tile_counts(dt):
     """Every K-loop shape of the software pipeline: 1, 2, 3 (tail paths), 4, 5, 7 and 16 K tiles, full and edge tiles."""
@@ -1026,7 +1079,11 @@ def test_weight_gradient_through_split_slabs_is_exact_and_repeatable():
     from case_rg_amd import _abi as A
     assert A.lib.case_abi_features() & A.FEAT_GEMM_DW_SLABS
     dt = torch.bfloat16
-    for (Mtok, N, K, split, bias) in ((64 * 64, 512, 512, 16, True), (64 * 96, 256, 768, 12, False), (64 * 27, 512, 256, 9, True)):
+    # the last two shapes give every persistent workgroup SEVERAL output tiles (45 tiles x 17 splits = 765, 30 x 23 = 690 on 256 CUs): the
+    # wait in front of a workgroup's 2nd .. nth tile counts the previous epilogue's stores (round 4 counted too many for the slab
+    # epilogue -- ADVICE r4 -- and the fragment reads could overtake the first DMAs; one tile per workgroup never reaches that wait)
+    for (Mtok, N, K, split, bias) in ((64 * 64, 512, 512, 16, True), (64 * 96, 256, 768, 12, False), (64 * 27, 512, 256, 9, True),
+                                      (64 * 17 * 3, 768, 3840, 17, True), (64 * 23, 1536, 1280, 23, False)):
         g, x = _rand(Mtok, N, dt=dt, seed=1), _rand(Mtok, K, dt=dt, seed=2, scale=Mtok ** -0.5)
         ref = g.float().t() @ x.float()
         d = A.GemmDesc()

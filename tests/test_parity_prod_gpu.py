@@ -39,6 +39,9 @@ MODES = {
 # errors are pinned by test_bf16_auto_full_gradients_are_uniformly_close_to_the_oracle below.
 BF16_BARS = {"prod_case_train": (2e-2, {"bf16_auto": 0.11, "bf16_large_fused": 0.13, "bf16_small_unfused": 0.095}),
              "prod_masque_train": (2e-2, {"bf16_auto": 0.115, "bf16_large_fused": 0.185, "bf16_small_unfused": 0.145}),
+             # the ten-passage items: bars start from the two-passage fixtures' (same depth of ReLU blocks), re-derived from the ledger
+             "prod_case_train_p10": (2e-2, {"bf16_auto": 0.13, "bf16_large_fused": 0.15, "bf16_small_unfused": 0.12}),
+             "prod_masque_train_p10": (2e-2, {"bf16_auto": 0.13, "bf16_large_fused": 0.185, "bf16_small_unfused": 0.145}),
              "cfg5_case_train": (2e-2, {"bf16_auto": 0.15, "bf16_large_fused": 0.2, "bf16_small_unfused": 0.15}),
              "cfg5_masque_train": (2e-2, {"bf16_auto": 0.15, "bf16_large_fused": 0.2, "bf16_small_unfused": 0.15}),
              "cfg5_block_5h": (1.5e-2, 0.135), "cfg5_block_h": (1.5e-2, 0.16),           # one ReLU block (measured 0.088 / 0.106)
@@ -52,7 +55,7 @@ BF16_BARS = {"prod_case_train": (2e-2, {"bf16_auto": 0.11, "bf16_large_fused": 0
 # in K order inside each accumulator (2.2e-3 of the slice's scale on its worst element; the tensor's norm agrees to 3.0e-4).
 FP32_OVERRIDES = {("cfg5_masque_train", "gslice_passage_selection.interaction.dual_att_linear.weight"): 4e-3}
 
-HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "cfg5_case_train": (96, 480), "cfg5_masque_train": (96, 480), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
+HEAD_DIMS = {"prod_case_train": (64, 320), "prod_masque_train": (64, 320), "prod_case_train_p10": (64, 320), "prod_masque_train_p10": (64, 320), "cfg5_case_train": (96, 480), "cfg5_masque_train": (96, 480), "cfg5_block_5h": (480,), "cfg5_block_h": (96,),
              "cfg5_dec_layer_long_memory": (96,), "prod_enc_layer": (64,), "prod_block_5h": (320,)}
 
 
@@ -127,6 +130,8 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
         assert 256 not in m.tiles and m.calls.get("case_attention_fwd", 0) == 0
     if mode == "bf16_auto" and name.endswith("_train"):
         assert 256 in m.tiles and m.calls.get("case_attention_bwd", 0) > 0, "bench-mode kernels (gemm8w, fa_bwd) did not run"
+    if mode == "bf16_auto" and name.endswith("_p10"):  # the decoder's cross-attention over the 3840-token memory, as bench.py times it
+        assert m.calls.get("case_attention_fwd_splitkv", 0) > 0, "the split-KV cross-attention forward did not run at S = 3840"
 
 
 # bf16 bars of the greedy fixtures, from the measured errors (profiles/r03_parity_errors.json): probabilities behind the 40x-sharpened

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-basic-block instruction census of one kernel in a hipcc -save-temps .s file:  asm_blocks.py file.s <mangled-name-substring>"""
 import re
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Instruction-order sketch of the MFMA-bearing basic blocks of one kernel:  asm_pattern.py file.s <name-substring> [min_mfma] [max_blocks]
 M = MFMA, r / w = LDS read / write, g = global or buffer load, e = v_exp, a = v_accvgpr, . = other VALU, s = scalar, B = barrier,
 |...| = s_waitcnt (L = lgkmcnt, V = vmcnt)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Condensed instruction stream of a kernel's MFMA region from hipcc -S output (runs of equal opcodes folded)."""
 import sys
 lines = open(sys.argv[1]).read().split('\n')

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Micro-benchmark of the fused attention kernels: self-attention on the cfg 2 / cfg 5 passage shapes and the long-memory
 cross-attention of the decoder.  `python tools/attn_bench.py [p_drop]`; one JSON line per case."""
 import json

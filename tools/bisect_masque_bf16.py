@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """where does the bf16_auto gradient error of prod_masque_train come from (0.148 on
 response_generation.decoder.attns.1.linear_key.weight, 0.107 on query_encoder.embedding.0.weight)?
 Runs the production-shape Masque fixture's model on the CPU oracle (f32) and on the product in bf16_auto, prints the FULL-tensor

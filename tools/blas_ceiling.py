@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Calibration only (never on the product path): what the vendor GEMM (hipBLASLt behind torch.matmul) reaches on this box at the
 shapes of CaSE cfg 2, next to this library's kernels on the same tensors.  Tells how much of the gap to the 2.5 PFLOP/s bf16 peak
 is the chip's clock under MFMA load and how much is ours.

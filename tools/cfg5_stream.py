@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Only the cfg 5 decoder cross-attention (4 items x 40 queries over the 20 480-token memory, head_dim 96): the launch whose K / V stream
 bench.py --mode cfg5 reports as its HBM roofline.  Profiled with two rocprofv3 PMC passes for `traffic` (tools/pmc_traffic.py)."""
 import os

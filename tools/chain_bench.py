@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Times the fused encoder chain kernels (csrc/encoder_chain.hip) alone on random data: python tools/chain_bench.py [rows] [iters]
 Prints one JSON line per variant: ms, TFLOP/s of the GEMM work it contains, fraction of the bf16 MFMA peak.
 CASE_HIP_LIB selects another build of the library (A/B of kernel variants)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Compares each variant of the fused encoder chain with the same arithmetic done by torch on the GPU (f32 from the bf16 inputs); prints the
 worst error and where non-finite values sit (token rows / feature columns)."""
 import os

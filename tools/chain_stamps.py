@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Reads the s_memtime stamps a -DCHAIN_STAMPS build of csrc/encoder_chain.hip leaves in the tail of qkv_out (diagnostic build only,
 CASE_HIP_LIB=...): per-phase cycles of wave STAMP_WAVE on each workgroup's second tile, median over workgroups.
 Stamp ids: 0 tile start, 1 own DMA rows landed, 2 barrier passed, then per stage st: 3+4st K loop done, 4+4st barrier passed (stages 0-2),

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Interleaved A/B timing of K18 builds (tools/fa64_variant.sh) in ONE process per library is impossible with ctypes (one library per
 process), so each variant runs in its own child, three rounds interleaved: `python tools/fa64_ab.py p_drop lib1 lib2 ...`."""
 import json, os, subprocess, sys

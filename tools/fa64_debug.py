@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Smallest call of K18 (one workgroup per item, no dropout by default): prints the error against the f32 reference."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

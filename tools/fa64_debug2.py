@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-sequence error of K18 under a few validity patterns (debugging aid)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Gradient errors of K19 per output and head (debugging aid)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Phase anatomy of K18 (csrc/attn64.hip) from s_memtime stamps: builds a -DFA64_STAMPS copy of the library into gpurun_out/,
 runs the cfg 2 self-attention forward and prints, per wave of workgroup 0 and interval, the cycles of phase work, of the counted
 vmcnt wait and of the barrier wait.  `python tools/fa64_stamps.py [p_drop]` (on the GPU box)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Debug aid: run the 256-tile GEMM on small shapes repeatedly and report where it disagrees with torch (16x16 block map)."""
 import os, sys
 import torch

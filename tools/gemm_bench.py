@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Micro-benchmark of the MFMA GEMM family on the shapes that dominate CaSE cfg 2 (random bf16 data).
     python tools/gemm_bench.py            # prints TFLOP/s per shape / layout
 """

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Fixed vs per-K-tile cost of the GEMM tilings: time M x N x K for growing K (NT, bf16).  python tools/gemm_ksweep.py [N]"""
 import os
 import sys

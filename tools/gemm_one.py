@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """One GEMM shape, a few launches: target for rocprofv3 --pmc runs."""
 import os
 import sys

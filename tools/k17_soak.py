@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Soak of K17 in ONE process: 40 rounds of the cfg-2-geometry forward / backward / products on fresh random inputs, each round checked
 bit for bit against a second launch of the same inputs (no atomics anywhere: any difference is a race)."""
 import math

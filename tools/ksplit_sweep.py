@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Split-KV sweep of the long-memory cross-attention forward (cfg 5: 4 x 40 queries over 20 480 keys, head_dim 96; cfg 2 decoder: 32 x 40 over 3840, head_dim 64)."""
 import os, sys
 import torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-step kernel time table from a rocprofv3 --kernel-trace --stats CSV: python tools/kstats.py <kernel_stats.csv> <steps incl. warm-up + instrumented> [top]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """LayerNorm<5H> backward + concat5 backward: the two kernels against the fused one (case_layernorm_bwd_concat5) at cfg 2's shape."""
 import os, sys
 import torch

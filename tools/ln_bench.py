@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Micro-benchmark of the LayerNorm / column-sum kernels at the cfg 2 shapes (achieved HBM GB/s on algorithmic bytes)."""
 import json
 import os

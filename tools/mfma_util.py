@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """MFMA utilisation per kernel from one rocprofv3 PMC pass:
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d DIR -o m -- python3 tools/blas_ceiling.py
     python tools/mfma_util.py DIR/m_counter_collection.csv out.json

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """HBM traffic per launch of the GEMM kernels from two rocprofv3 PMC passes of bench.py.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1
@@ -61,6 +60,11 @@ def load(path, counter):
 
 def main():
     fpath, wpath, out = sys.argv[1:4]
+    # optional 4th / 5th argument: the workload key bench.py matches against (its `workload_key`, e.g. "case/b32/h512/p10x384/enc6/bf16")
+    # and the profiled command as it was run; bench.py refuses a file whose workload differs from the run it is printing
+    workload = sys.argv[4] if len(sys.argv) > 4 else "case/b32/h512/p10x384/enc6/bf16"
+    command = sys.argv[5] if len(sys.argv) > 5 else "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+
     f, w = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
     res = {}
     for k in sorted(set(f) | set(w)):
@@ -68,7 +72,7 @@ def main():
         wb = w[k][0] / max(1, w[k][1])
         res[k] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb),
                   "launches_fetch_pass": f[k][1], "launches_write_pass": w[k][1]}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1`",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes) -- " + command, "workload": workload,
                "corrections": "KiB -> bytes; FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64 bytes)", "kernels": res},
               open(out, "w"), indent=1)
     for k, v in res.items():

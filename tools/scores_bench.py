@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """K17 (attention scores with the softmax in the GEMM) against the two-kernel path it replaces, at the cfg 2 block geometry
 (320 sequences x 8 heads x 384 x 384, head_dim 320, dropout 0.1): ms per call of the forward (scores -> P, Pd) and backward (dO, V, P -> dS)."""
 import json

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-phase cycles of K17 (csrc/attn_scores.hip built with -DSC_STAMPS [-DSC_STAMP_WAVE=w], CASE_HIP_LIB=...): s_memtime stamps of one
 wave on each workgroup's second item, median over workgroups.  argv[1]: fwd | bwd."""
 import ctypes

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Split-K sweep of the weight-gradient GEMM (TN, f32 atomics) on the 128x128 and the 256x256 tiling."""
 import os, sys
 import torch
