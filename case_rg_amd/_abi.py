@@ -12,11 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CASE_HIP_LIB: another build of the same library (A/B measurements of kernel variants); there is still no non-HIP path
 LIB_PATH = os.environ.get("CASE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcase_hip.so")
 
-ABI_VERSION = 400  # include/case_hip.h CASE_ABI_VERSION this binding was written against
+ABI_VERSION = 500  # include/case_hip.h CASE_ABI_VERSION this binding was written against
 F32, BF16 = 0, 1
 WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
 (FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
- FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN) = (1 << i for i in range(10))
+ FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA) = (1 << i for i in range(11))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "case_encoder_chain": [C.POINTER(EncoderChainDesc)] + [ptr] * 14,
     "case_decoder_chain": [C.POINTER(DecoderChainDesc)] + [ptr] * 19,
     "case_set_reserved_cus": [i32],
+    "case_attention_decode_mqa": [ptr, ptr, ptr, ptr, i64, i64, i64, i32, ptr, i64, ptr],
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
     "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
 }
@@ -138,6 +139,10 @@ def _load():
     lib.case_encoder_chain_packed_bytes.argtypes = []
     lib.case_attention_bwd_scratch_floats.restype = C.c_int64
     lib.case_attention_bwd_scratch_floats.argtypes = [C.POINTER(AttnDesc)]
+    lib.case_attention_decode_mqa_workspace.restype = C.c_int64
+    lib.case_attention_decode_mqa_workspace.argtypes = [i64, i64, i32]
+    lib.case_attention_decode_mqa_splits.restype = C.c_int32
+    lib.case_attention_decode_mqa_splits.argtypes = [i64, i64]
     lib.case_abi_features.restype = C.c_uint32
     lib.case_abi_features.argtypes = []
     lib.case_get_reserved_cus.restype = C.c_int

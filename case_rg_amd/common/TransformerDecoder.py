@@ -16,6 +16,14 @@ from .Highway import Highway
 from .TransformerEncoder import _check_activation, _get_clones
 
 
+class RawMemory(object):
+    """What TransformerDecoder.project_memory hands the greedy loop instead of per-layer K / V projections when the absorbed form (K21,
+    ops.attention_decode_mqa) applies: the memory rows themselves, shared by every layer."""
+
+    def __init__(self, rows):
+        self.rows = rows
+
+
 class TransformerDecoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
         super().__init__()
@@ -55,7 +63,10 @@ class TransformerDecoderLayer(nn.Module):
         ctx = ops.attention(qkv, self_kv, self_kv, 0, 0, E, sa.num_heads, sa.head_dim, key_valid=hist_valid)
         x = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x)
         x = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x = ca.cross_attention(x, None, memory_valid, residual=x, kv=memory_kv)
+        if isinstance(memory_kv, RawMemory):  # K21: attend the raw memory rows with the K / V projections absorbed into q and the output
+            x = ca.cross_attention_absorbed(x, memory_kv.rows, memory_valid, residual=x)
+        else:
+            x = ca.cross_attention(x, None, memory_valid, residual=x, kv=memory_kv)
         x = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
                        residual=x)
@@ -135,8 +146,13 @@ class TransformerDecoder(nn.Module):
                                           normed=i > 0, next_norm=tail if nxt is None else (nxt.weight, nxt.bias, nxt.eps))
         return x
 
-    def project_memory(self, memory):
-        """Per-layer K/V projections of a memory (constant across greedy steps)."""
+    def project_memory(self, memory, absorb=False):
+        """Per-layer K/V projections of a memory (constant across greedy steps).  ``absorb`` (the greedy loop): for a long bf16 memory no
+        projection is cached at all -- every layer's step attends the raw rows (RawMemory; half the bytes per step, no 2 E-wide caches)."""
+        first = self.layers[0].multihead_attn
+        if absorb and ops.decode_absorb_supported(memory, first.embed_dim, first.num_heads):
+            raw = RawMemory(memory if memory.is_contiguous() else memory.contiguous())
+            return [raw for _ in self.layers]
         return [layer.multihead_attn.project_memory(memory) for layer in self.layers]
 
     def new_self_cache(self, batch, max_len, like):
@@ -174,7 +190,7 @@ class TransformerDecoder(nn.Module):
 
     def step(self, x, t, self_kvs, hist_valid, memory_kvs, memory_valid):
         first = self.layers[0]
-        if (x.shape[1] == 1 and not self.training and all(kv.is_contiguous() for kv in self_kvs)
+        if (x.shape[1] == 1 and not self.training and not isinstance(memory_kvs[0], RawMemory) and all(kv.is_contiguous() for kv in self_kvs)
                 and ops.decoder_chain_supported(x, first.self_attn.embed_dim, first.linear1.out_features, first.activation)
                 and all(l.self_attn.embed_dim == 512 and l.linear1.out_features == 512 and l.activation == "gelu" for l in self.layers)):
             x = self._step_chained(x, t, self_kvs, hist_valid, memory_kvs, memory_valid)

@@ -125,9 +125,9 @@ class PointerDecoderCore(nn.Module):
             return ops.SortedSource(source_map, self.tgt_vocab_size)
         return source_map
 
-    def _memory_cache(self, mems):
+    def _memory_cache(self, mems, absorb=False):
         """Step-invariant projections of the memories (cross-attention K/V per layer, additive-attention keys)."""
-        return [dict(kvs=self.decs[i].project_memory(m), uh=self.attns[i].project_keys(m)) for i, m in enumerate(mems)]
+        return [dict(kvs=self.decs[i].project_memory(m, absorb=absorb), uh=self.attns[i].project_keys(m)) for i, m in enumerate(mems)]
 
     def _run_prefix(self, dec_ids, mems, valid, weights, feature, cache=None):
         """decs[0] -> attns[0] -> decs[1] -> attns[1] (a sequential chain, CaSE/Model.py:74-83)."""
@@ -156,7 +156,7 @@ class PointerDecoderCore(nn.Module):
         the additive-attention keys are cached, so a step streams the caches once instead of recomputing the prefix
         (O(T) instead of O(T^2) decoder work, no per-step projection of the 3840-token passage memory)."""
         B, dev = mems[0].shape[0], mems[0].device
-        cache = self._memory_cache(mems)
+        cache = self._memory_cache(mems, absorb=not self.training)
         self_kvs = [dec.new_self_cache(B, max_target_length, mems[0]) for dec in self.decs]
         hist_valid = torch.zeros(B, max_target_length, dtype=torch.bool, device=dev)
         table, pos = self.embedding[0].weight, self.embedding[1]

@@ -53,6 +53,45 @@ class MultiheadAttention(nn.Module):
         E = self.embed_dim
         return ops.linear(memory, self.in_proj_weight[E:], self.in_proj_bias[E:])
 
+    # -- K21: decode-time cross-attention on the raw memory (absorbed K / V projections) ------------
+    def absorbed(self):
+        """The layer's projections folded for ops.attention_decode_mqa (inference; rebuilt when a parameter changes):
+          wqk [heads E, E] bf16, bqk [heads E] f32:  qp_h = log2(e) / sqrt(d) Wk_h^T (Wq_h x + bq_h)   (q_h . bk_h is constant over the keys)
+          wv  [E, E] bf16 (the V rows of in_proj_weight, head h = rows h d .. h d + d - 1: o_h = Wv_h c_h)
+          bo  [E] f32 = out_proj.bias + out_proj.weight bv   (the probabilities of a row sum to one)"""
+        E, h, d = self.embed_dim, self.num_heads, self.head_dim
+        stamp = (ops.PARAM_EPOCH, self.in_proj_weight._version, self.in_proj_weight.data_ptr(), self.in_proj_bias._version,
+                 self.out_proj.weight._version, self.out_proj.bias._version, self.out_proj.weight.data_ptr())
+        hit = getattr(self, "_absorbed", None)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            w, b = self.in_proj_weight.detach(), self.in_proj_bias.detach()
+            c = 1.4426950408889634 / (d ** 0.5)
+            wqk = torch.empty(h, E, E, dtype=torch.float32, device=w.device)
+            # per head: Wk_h^T [E, d] x Wq_h [d, E], exact-f32 MFMA path; A = rows E + h d .. of w read k-major, B = rows h d .. read k-major
+            ops.gemm(w, w, wqk, E, E, d, E, E, E, a_off=E * E, a_kmajor=True, b_kmajor=True, batch1=h, sa=(d * E, 0), sb=(d * E, 0),
+                     sc=(E * E, 0), alpha=c)
+            bqk = (w[E:2 * E].reshape(h, d, E) * b[:E].reshape(h, d, 1)).sum(dim=1).mul_(c).reshape(h * E).contiguous()
+            bo = (self.out_proj.bias.detach() + (self.out_proj.weight.detach() * b[2 * E:].reshape(1, E)).sum(dim=1)).contiguous()
+            pack = dict(wqk=ops.cast(wqk.reshape(h * E, E), torch.bfloat16), bqk=bqk.float(), bo=bo.float(),
+                        wv=ops.cast_param(self.in_proj_weight[2 * E:], torch.bfloat16), wo=ops.cast_param(self.out_proj.weight, torch.bfloat16))
+        self._absorbed = (stamp, pack)
+        return pack
+
+    def cross_attention_absorbed(self, x, memory, memory_valid=None, residual=None):
+        """x [N, 1, E] (one decode position per sequence), memory [N, S, E] RAW bf16 rows -> out_proj(attention) (+ residual)."""
+        E, h, d = self.embed_dim, self.num_heads, self.head_dim
+        N = x.shape[0]
+        pk = self.absorbed()
+        qp = ops.linear(x.reshape(N, E), pk["wqk"], pk["bqk"])            # [N, heads E]
+        ctx = ops.attention_decode_mqa(qp, memory, memory_valid)          # [N, heads E]: head h's context at columns E h ..
+        o = torch.empty(N, E, dtype=ctx.dtype, device=ctx.device)
+        # o[:, h d .. h d + d) = ctx[:, E h .. E h + E) Wv_h^T, the eight heads as one batched launch
+        ops.gemm(ctx, pk["wv"], o, N, d, E, h * E, E, E, batch1=h, sa=(E, 0), sb=(d * E, 0), sc=(d, 0))
+        res2 = None if residual is None else residual.reshape(N, E)
+        return ops.linear(o, pk["wo"], pk["bo"], residual=res2).reshape(N, 1, E)
+
     def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None, ln=None):
         """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention); ``ln``: see self_attention."""
         E = self.embed_dim

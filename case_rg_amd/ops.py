@@ -1037,6 +1037,34 @@ class AttentionFn(Function):
         return (out[0], out[1], out[2]) + (None,) * 8
 
 
+# K21: the greedy step's cross-attention over a long memory on the RAW memory rows with absorbed K / V projections (csrc/attn_mqa.hip).
+# "auto": bf16, width 512, 8 heads, memories of >= DECODE_ABSORB_MIN_KEYS keys, inference; "off": the cached K / V projections (K13).
+DECODE_ABSORB = os.environ.get("CASE_DECODE_ABSORB", "auto")
+DECODE_ABSORB_MIN_KEYS = 1024
+
+
+def decode_absorb_supported(memory, embed_dim, heads):
+    return (DECODE_ABSORB != "off" and torch.is_tensor(memory) and memory.is_cuda and memory.dtype == torch.bfloat16 and memory.dim() == 3
+            and embed_dim == 512 and heads == 8 and memory.shape[2] == 512 and memory.shape[1] >= DECODE_ABSORB_MIN_KEYS
+            and bool(A.lib.case_abi_features() & A.FEAT_ATTN_DECODE_MQA))
+
+
+def attention_decode_mqa(qp, memory, key_valid=None):
+    """qp [B, 8 * 512] bf16: per head the absorbed query log2(e) / sqrt(d) * Wk_h^T q_h; memory [B, S, 512] bf16 (keys AND values);
+    key_valid [B, S] bool -> [B, 8 * 512] bf16, head h's context sum_j p_hj memory_j at columns 512 h .. (no autograd: inference)."""
+    B, S, E = memory.shape
+    if qp.dtype != torch.bfloat16 or memory.dtype != torch.bfloat16 or E != 512 or qp.numel() != B * 8 * E:
+        raise TypeError("attention_decode_mqa: bf16 [B, 8 * 512] queries against a bf16 [B, S, 512] memory")
+    qp = qp if qp.is_contiguous() else qp.contiguous()
+    memory = memory if memory.is_contiguous() else memory.contiguous()
+    out = torch.empty(B, 8 * E, dtype=torch.bfloat16, device=memory.device)
+    nsplit = A.lib.case_attention_decode_mqa_splits(B, S)
+    need = A.lib.case_attention_decode_mqa_workspace(B, S, nsplit)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=memory.device) if need else None
+    A.call("case_attention_decode_mqa", _ptr(qp), _ptr(memory), _ptr(_u8(key_valid)), _ptr(out), B, S, 8 * E, nsplit, _ptr(ws), need, _stream())
+    return out
+
+
 def attention(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid=None, causal=False, p_drop=0.0):
     return AttentionFn.apply(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, _u8(key_valid), causal, p_drop)
 

@@ -43,8 +43,9 @@ enum {
 /* ABI generation.  case_version() returns the CASE_ABI_VERSION the library was built from; a binder compares it with the header it was
  * written against (case_rg_amd/_abi.py refuses any other library).  Bumped with every struct or signature change:
  *   100 round 1 | 200 round 2 (case_gemm_dw_bias, decode, optimizer) | 300 round 3 (CaseOptTensor 56 -> 64 bytes, K16 / K17)
- *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs). */
-#define CASE_ABI_VERSION 400
+ *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs)
+ *   500 round 5 (K21 case_attention_decode_mqa, ...). */
+#define CASE_ABI_VERSION 500
 int case_version(void);
 /* what the build contains, as a bit mask */
 enum {
@@ -57,7 +58,8 @@ enum {
   CASE_FEAT_ATTN_RESIDENT = 1u << 6,   /* K18 / K19 behind case_attention_fwd / _bwd */
   CASE_FEAT_RESERVED_CUS = 1u << 7,    /* case_set_reserved_cus */
   CASE_FEAT_GEMM_DW_SLABS = 1u << 8,   /* case_gemm_dw_slabs: atomics-free, run-to-run deterministic split-K weight gradients */
-  CASE_FEAT_DECODER_CHAIN = 1u << 9    /* K20 case_decoder_chain */
+  CASE_FEAT_DECODER_CHAIN = 1u << 9,   /* K20 case_decoder_chain */
+  CASE_FEAT_ATTN_DECODE_MQA = 1u << 10 /* K21 case_attention_decode_mqa */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -260,6 +262,19 @@ int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, const void*
 int case_attention_decode_supported(int64_t head_dim);
 int case_attention_decode(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                           void* out, case_stream_t stream);
+/* K21, the decode step's cross-attention over a LONG memory with absorbed projections (round 5): multi-query attention of 8 query rows
+ * per item against the RAW memory rows [B, S, 512] (bf16), K = V = memory.  Replaces, for the layers of the passage-memory stack,
+ * in_proj(q) -> case_attention_decode over the layer's cached K / V projections -> (common/TransformerDecoder.py:81-82 at one position,
+ * CaSE/Model.py:94-123): with qp[b, h, :] = log2(e) / sqrt(d) * Wk_h^T q_h the scores q_h . K_h[j] equal qp_h . mem_j up to a term that
+ * is constant over j, and sum_j p_hj V_h[j] = Wv_h (sum_j p_hj mem_j) + bv_h -- the caller applies Wv_h (and its bias) to the result.
+ * One stream of S x 512 x 2 bytes per item instead of the two cached projections.  qp [B, 8, 512] bf16 (16-byte aligned), out [B, ldo] bf16
+ * (head h at columns 512 h .. 512 h + 511), key_valid [B, S] bytes or null; items without a valid key give exact zeros.  nsplit key
+ * ranges per item (case_attention_decode_mqa_splits picks one for (B, S); > 1 needs a workspace of case_attention_decode_mqa_workspace
+ * bytes, 16-byte aligned).  bf16, 8 heads, width 512 only. */
+int64_t case_attention_decode_mqa_workspace(int64_t B, int64_t S, int32_t nsplit);
+int32_t case_attention_decode_mqa_splits(int64_t B, int64_t S);
+int case_attention_decode_mqa(const void* qp, const void* mem, const uint8_t* key_valid, void* out, int64_t B, int64_t S, int64_t ldo,
+                              int32_t nsplit, void* workspace, int64_t workspace_bytes, case_stream_t stream);
 int case_attention_bwd_supported(int64_t head_dim);
 /* floats of scratch case_attention_bwd needs behind `delta` (2 N heads Lq: the resident single-pass backward of head_dim 64, K19,
  * keeps -lse / scale and -rowsum(dO * O) per query) */
