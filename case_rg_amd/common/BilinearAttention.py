@@ -23,6 +23,19 @@ class BilinearAttention(nn.Module):
         """uh = Wk k  [B, S, H] (constant across greedy steps)."""
         return ops.linear(key, self.linear_key.weight)
 
+    def project_keys_exp(self, key):
+        """e^{2 Wk k} in bf16 [B, S, H] for the fused decode step (K22): the exponential of the key half of tanh(wq + uh) is the same in
+        every greedy step, so it is taken once, from the f32 projection."""
+        return ops.additive_key_exp(ops.linear(key, self.linear_key.weight, out_dtype=torch.float32))
+
+    def attend_decode(self, query, value, row_valid, col_valid, eu, prior=None):
+        """One decode position per sequence: query [B, 1, Q] -> (ctx [B, 1, Hv], p or, with ``prior``, p prior / (1e-8 + sum p prior) [B, 1, S])."""
+        B = query.shape[0]
+        wq = ops.linear(query, self.linear_query.weight, self.linear_query.bias, out_dtype=torch.float32)
+        ctx, p, copy = ops.pointer_attend_decode(wq, eu, self.v.weight.detach().reshape(-1).float(), value, col_valid,
+                                                 None if row_valid is None else row_valid.reshape(B), prior)
+        return ctx.unsqueeze(1), (p if copy is None else copy).unsqueeze(1)
+
     def raw_scores(self, query, key=None, uh=None):
         wq = ops.linear(query, self.linear_query.weight, self.linear_query.bias, out_dtype=torch.float32)
         if uh is None:

@@ -127,7 +127,12 @@ class PointerDecoderCore(nn.Module):
 
     def _memory_cache(self, mems, absorb=False):
         """Step-invariant projections of the memories (cross-attention K/V per layer, additive-attention keys)."""
-        return [dict(kvs=self.decs[i].project_memory(m, absorb=absorb), uh=self.attns[i].project_keys(m)) for i, m in enumerate(mems)]
+        out = []
+        for i, m in enumerate(mems):
+            fused = absorb and ops.pointer_decode_supported(m) and self.attns[i].hidden_size == m.shape[2]  # K22: e^{2 uh} instead of uh
+            out.append(dict(kvs=self.decs[i].project_memory(m, absorb=absorb), uh=None if fused else self.attns[i].project_keys(m),
+                            eu=self.attns[i].project_keys_exp(m) if fused else None))
+        return out
 
     def _run_prefix(self, dec_ids, mems, valid, weights, feature, cache=None):
         """decs[0] -> attns[0] -> decs[1] -> attns[1] (a sequential chain, CaSE/Model.py:74-83)."""
@@ -176,11 +181,14 @@ class PointerDecoderCore(nn.Module):
             for i, mem in enumerate(mems):
                 x = self.decs[i].step(x, t, self_kvs[i], hist_valid, cache[i]["kvs"], valid[i])
                 q = x if feat is None else torch.cat([x, feat], dim=-1)
-                ctx, p = self.attns[i].attend(q, mem, mem, row_valid=tok_valid, col_valid=valid[i], uh=cache[i]["uh"])
+                if cache[i]["eu"] is not None:  # K22: scores, softmax, prior renormalisation and context in one launch
+                    ctx, p = self.attns[i].attend_decode(q, mem, tok_valid, valid[i], cache[i]["eu"], None if weights is None else weights[i])
+                else:
+                    ctx, p = self.attns[i].attend(q, mem, mem, row_valid=tok_valid, col_valid=valid[i], uh=cache[i]["uh"])
+                    if weights is not None:
+                        p = weights[i].unsqueeze(1) * p
+                        p = p / (1e-8 + p.sum(dim=-1, keepdim=True))
                 ctxs.append(ctx)
-                if weights is not None:
-                    p = weights[i].unsqueeze(1) * p
-                    p = p / (1e-8 + p.sum(dim=-1, keepdim=True))
                 copies.append(p)
             dec_out, gen, dist = self._head(dec_in, x, ctxs, copies, feat, source_map)
             ids = ops.row_argmax(dist[:, -1])[0].unsqueeze(1)

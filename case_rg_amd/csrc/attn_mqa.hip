@@ -249,7 +249,7 @@ extern "C" int64_t case_attention_decode_mqa_workspace(int64_t B, int64_t S, int
 
 // how many key ranges per item the launch below should use for (B, S): enough workgroups for the chip, ranges of whole 32-key tiles that
 // fit the kernel's validity stage
-extern "C" int32_t case_attention_decode_mqa_splits(int64_t B, int64_t S) {
+extern "C" int case_attention_decode_mqa_splits(int64_t B, int64_t S) {
   if (B <= 0 || S <= 0) return 1;
   const int cus = case_device_cus();
   int64_t n = B >= cus ? 1 : (cus + B - 1) / B;
@@ -257,7 +257,7 @@ extern "C" int32_t case_attention_decode_mqa_splits(int64_t B, int64_t S) {
   if (n > tiles / 4) n = tiles / 4 > 0 ? tiles / 4 : 1;  // at least four tiles per range
   const int64_t need = (S + mqa::MAX_KEYS - 1) / mqa::MAX_KEYS;
   if (n < need) n = need;
-  return (int32_t)n;
+  return (int)n;
 }
 
 extern "C" int case_attention_decode_mqa(const void* qp, const void* mem, const uint8_t* key_valid, void* out, int64_t B, int64_t S,

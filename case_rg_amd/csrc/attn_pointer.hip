@@ -251,6 +251,172 @@ __global__ __launch_bounds__(256) void additive_bwd_wq_kernel(const float* __res
   }
 }
 
+// ---- K22 (round 5): the greedy step's additive attention as ONE launch ------------------------------------------------------------
+// tanh(a + b) = 1 - 2 / (e^{2a} e^{2b} + 1): with EU = e^{2 uh} cached per (source position, feature) when the memory is encoded (uh is
+// the same in all T steps) and EW = e^{2 wq} computed once per (item, feature) per step, an element costs one FMA, ONE reciprocal and
+// one FMA -- the exponentials move from O(T S H) to O((T + S) H).  Both arguments are clamped at +-EXP_CLAMP so that the product stays
+// finite and normal in f32 (e^{+-86}); that changes tanh(wq + uh) only where |wq| or |uh| exceeds 21.5, far outside what a linear map of
+// LayerNorm outputs produces (and there tanh is saturated unless the two nearly cancel).
+// One workgroup of 16 waves per item: (1) scores over the EU rows into LDS, (2) masked softmax in LDS (+ the copy prior's
+// renormalisation p w / (1e-8 + sum p w), CaSE/Model.py:81-82), (3) ctx = sum_j p_j value_j over the memory rows -- the score sweep, the
+// softmax, the cast and the [1, S] x [S, H] product of the four-launch form, and the four ATen launches of the prior.  Rows of masked
+// source positions are never loaded.  HBM-bound: S H (2 + 2) bytes per item.
+constexpr float EXP_CLAMP = 43.f;
+constexpr int PA_WAVES = 16, PA_H = 512;
+
+__global__ __launch_bounds__(256) void additive_key_exp_kernel(const float* __restrict__ uh, bf16_t* __restrict__ eu, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(uh)[2 * i], b = reinterpret_cast<const float4*>(uh)[2 * i + 1];
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = __expf(fminf(fmaxf(2.f * x[e], -EXP_CLAMP), EXP_CLAMP));
+    Vec16<bf16_t>::store(eu + 8 * i, y);
+  }
+}
+
+// sums of four per-lane values over the 64 lanes, all at once: two v_permlane32_swap + one v_permlane16_swap fold the wave's four
+// 16-lane rows so that lane row g keeps value g, four rotate-adds inside the row finish it.  Returns the total of r<g> in every lane of
+// lane row g (lanes 16 g .. 16 g + 15).
+__device__ __forceinline__ float row_sum4(float r0, float r1, float r2, float r3) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);  // [r0.lo | r2.lo], [r0.hi | r2.hi]
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+  const float A = __uint_as_float(a[0]) + __uint_as_float(a[1]);  // lanes 0-31: r0 over {l, l + 32}; lanes 32-63: r2
+  const float B = __uint_as_float(b[0]) + __uint_as_float(b[1]);  // r1 | r3
+  const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(A), __float_as_uint(B), false, false);
+  float t = __uint_as_float(c[0]) + __uint_as_float(c[1]);        // lane row 0: r0, 1: r1, 2: r2, 3: r3 (16 partial sums each)
+  t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x128, 0xf, 0xf, false));  // row_ror:8
+  t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x124, 0xf, 0xf, false));  // row_ror:4
+  t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x122, 0xf, 0xf, false));  // row_ror:2
+  t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return t;
+}
+
+__global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
+    const float* __restrict__ wq, const bf16_t* __restrict__ eu, const float* __restrict__ v, const bf16_t* __restrict__ mem,
+    const uint8_t* __restrict__ col_valid, const uint8_t* __restrict__ row_valid, const float* __restrict__ prior, bf16_t* __restrict__ ctx,
+    float* __restrict__ p_out, float* __restrict__ copy_out, const int64_t S) {
+  extern __shared__ __attribute__((aligned(16))) float pa_smem[];
+  float* sc = pa_smem;                              // [S] scores, then probabilities
+  float* red = pa_smem + ((S + 3) & ~(int64_t)3);   // [PA_WAVES][PA_H] partial contexts; its head doubles as the reduction scratch
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  const uint8_t* cv = col_valid ? col_valid + b * S : nullptr;
+  const bool row_ok = row_valid ? row_valid[b] != 0 : true;
+  float ew[8], vv[8];
+  {
+    float w8[8];
+    Vec16<float>::load(wq + b * PA_H + 8 * lane, *reinterpret_cast<float(*)[4]>(w8));
+    Vec16<float>::load(wq + b * PA_H + 8 * lane + 4, *reinterpret_cast<float(*)[4]>(w8 + 4));
+    Vec16<float>::load(v + 8 * lane, *reinterpret_cast<float(*)[4]>(vv));
+    Vec16<float>::load(v + 8 * lane + 4, *reinterpret_cast<float(*)[4]>(vv + 4));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ew[e] = __expf(fminf(fmaxf(2.f * w8[e], -EXP_CLAMP), EXP_CLAMP));
+  }
+  float vs = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) vs += vv[e];
+  vs = wave_sum(vs);
+  // (1) s_j = sum_h v_h tanh(wq_h + uh_jh) = sum_h v_h - 2 sum_h v_h / (EW_h EU_jh + 1).  A wave takes four rows at a time (16 bytes of
+  // each per lane) and sums them with ONE transposing reduction (row_sum4): six ds_bpermute steps per row were costing the stage
+  // more than its reciprocals -- the first build spent 0.28 ms per launch in them, above its HBM time.  The next four rows are
+  // requested before the current four are evaluated.
+  const bf16_t* eub = eu + b * S * PA_H + 8 * lane;
+  uint4 raw[4], nxt[4];
+  bool ok[4], nok[4];
+#define PA_LOAD(R, OK, J0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                              \
+    const int64_t j = (J0) + u * PA_WAVES;                                     \
+    OK[u] = j < S && (!cv || cv[j]); /* wave-uniform */                        \
+    if (OK[u]) R[u] = *reinterpret_cast<const uint4*>(eub + j * PA_H);         \
+  }
+  PA_LOAD(raw, ok, (int64_t)wave)
+  for (int64_t j0 = wave; j0 < S; j0 += 4 * PA_WAVES) {
+    PA_LOAD(nxt, nok, j0 + 4 * PA_WAVES)
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r[u] = 0.f;
+      if (ok[u]) {
+        float x[8];
+        Vec16<bf16_t>::unpack(raw[u], x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[u] += vv[e] * __builtin_amdgcn_rcpf(fmaf(ew[e], x[e], 1.f));
+      }
+    }
+    const float tot = row_sum4(r[0], r[1], r[2], r[3]);  // lane row g holds the sum of r[g]
+    const int g = lane >> 4;
+    const int64_t j = j0 + g * PA_WAVES;
+    const bool okg = g == 0 ? ok[0] : g == 1 ? ok[1] : g == 2 ? ok[2] : ok[3];
+    if ((lane & 15) == 0 && j < S) sc[j] = okg ? vs - 2.f * tot : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      raw[u] = nxt[u];
+      ok[u] = nok[u];
+    }
+  }
+#undef PA_LOAD
+  __syncthreads();
+  // (2) masked softmax over the S scores (exact zeros for a row without a valid key or an invalid target row)
+  float mx = -INFINITY;
+  for (int64_t j = threadIdx.x; j < S; j += 64 * PA_WAVES) mx = fmaxf(mx, sc[j]);
+  mx = block_max(mx, red);
+  float sum = 0.f;
+  for (int64_t j = threadIdx.x; j < S; j += 64 * PA_WAVES) {
+    const float e = mx == -INFINITY ? 0.f : __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, red);
+  const float inv = (row_ok && sum > 0.f) ? 1.f / sum : 0.f;
+  float wsum = 0.f;
+  for (int64_t j = threadIdx.x; j < S; j += 64 * PA_WAVES) {
+    const float pj = sc[j] * inv;
+    sc[j] = pj;
+    p_out[b * S + j] = pj;
+    if (prior) wsum += pj * prior[b * S + j];
+  }
+  if (prior) {
+    wsum = block_sum(wsum, red);
+    const float winv = 1.f / (1e-8f + wsum);
+    for (int64_t j = threadIdx.x; j < S; j += 64 * PA_WAVES) copy_out[b * S + j] = sc[j] * prior[b * S + j] * winv;
+  }
+  __syncthreads();
+  // (3) ctx = sum_j p_j value_j; rows with p_j == 0 (masked positions) are not read
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const bf16_t* mb = mem + b * S * PA_H + 8 * lane;
+  for (int64_t j0 = wave; j0 < S; j0 += 4 * PA_WAVES) {
+    uint4 raw[4];
+    float pj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = j0 + u * PA_WAVES;
+      pj[u] = j < S ? sc[j] : 0.f;  // wave-uniform
+      if (pj[u] != 0.f) raw[u] = *reinterpret_cast<const uint4*>(mb + j * PA_H);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pj[u] != 0.f) {
+        float x[8];
+        Vec16<bf16_t>::unpack(raw[u], x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj[u], x[e], acc[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave * PA_H + 8 * lane + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < PA_H) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < PA_WAVES; ++w) t += red[w * PA_H + threadIdx.x];  // fixed order: bit-identical from launch to launch
+    ctx[b * PA_H + threadIdx.x] = f32_to_bf16(t);
+  }
+}
+
 // ---- K11 ---------------------------------------------------------------------------------------
 __global__ void copy_scatter_fwd_kernel(const int64_t* __restrict__ src, const float* __restrict__ w,
                                         float* __restrict__ dist, int64_t B, int64_t Tn, int64_t S, int64_t V) {
@@ -454,6 +620,37 @@ extern "C" int case_additive_scores_bwd(const float* ds, const float* wq, const 
     hipLaunchKernelGGL((additive_bwd_wq_kernel<bf16_t, true>), g2, dim3(256), 0, st, ds, wq, (const bf16_t*)uh, v, d_wq, T, S, H, tblocks, j_per);
   }
   return case_check_launch("case_additive_scores_bwd");
+}
+
+extern "C" int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_stream_t stream) {
+  CASE_REQUIRE(uh && eu && n > 0 && n % 8 == 0 && (uintptr_t)uh % 16 == 0 && (uintptr_t)eu % 16 == 0, "case_additive_key_exp: bad argument");
+  hipLaunchKernelGGL(additive_key_exp_kernel, dim3(grid_for(n / 8, 256, 1, 256 * 32)), dim3(256), 0, (hipStream_t)stream, uh,
+                     reinterpret_cast<bf16_t*>(eu), n / 8);
+  return case_check_launch("case_additive_key_exp");
+}
+
+extern "C" int case_pointer_attend_decode(const float* wq, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
+                                          const uint8_t* row_valid, const float* prior, void* ctx, float* p, float* copy, int64_t B, int64_t S,
+                                          int64_t H, case_stream_t stream) {
+  CASE_REQUIRE(wq && eu && v && value && ctx && p && B > 0 && S > 0 && B < (1ll << 31) && (copy != nullptr) == (prior != nullptr),
+               "case_pointer_attend_decode: bad argument");
+  if (H != PA_H || S > 28000)
+    return case_set_error(CASE_E_UNSUPPORTED, "case_pointer_attend_decode: built for H = %d and S <= 28000 (run case_additive_scores_fwd + "
+                                              "case_softmax_fwd + case_gemm)", PA_H);
+  for (const void* q : {(const void*)wq, eu, (const void*)v, value})
+    CASE_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "case_pointer_attend_decode: tensors must be 16-byte aligned");
+  const size_t lds = (size_t)(((S + 3) & ~(int64_t)3) + PA_WAVES * PA_H) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pointer_attend_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_pointer_attend_decode: cannot reserve LDS");
+    attr = true;
+  }
+  hipLaunchKernelGGL(pointer_attend_decode_kernel, dim3((unsigned)B), dim3(64 * PA_WAVES), lds, (hipStream_t)stream, wq,
+                     reinterpret_cast<const bf16_t*>(eu), v, reinterpret_cast<const bf16_t*>(value), col_valid, row_valid, prior,
+                     reinterpret_cast<bf16_t*>(ctx), p, copy, S);
+  return case_check_launch("case_pointer_attend_decode");
 }
 
 extern "C" int case_copy_scatter_fwd(const int64_t* src, const float* w, float* dist, int64_t B, int64_t T, int64_t S,

@@ -1643,6 +1643,44 @@ def additive_scores(wq, uh, v):
 # ----------------------------------------------------------------------------------------------
 # K11 pointer scatter / K12 NLL / K13 argmax
 # ----------------------------------------------------------------------------------------------
+# K22: the greedy step's additive attention (scores + masked softmax + prior renormalisation + context) as one launch over the cached
+# e^{2 uh} rows (csrc/attn_pointer.hip).  "auto": bf16 memories of width 512, batches of >= POINTER_FUSED_MIN_BATCH items (one workgroup
+# per item: a small batch is faster on the multi-workgroup kernels); "off": scores -> softmax -> cast -> product.
+POINTER_FUSED = os.environ.get("CASE_POINTER_FUSED", "auto")
+POINTER_FUSED_MIN_BATCH = 96
+
+
+def pointer_decode_supported(memory):
+    return (POINTER_FUSED != "off" and torch.is_tensor(memory) and memory.is_cuda and memory.dtype == torch.bfloat16 and memory.dim() == 3
+            and memory.shape[2] == 512 and memory.shape[1] <= 28000 and memory.shape[0] >= POINTER_FUSED_MIN_BATCH
+            and bool(A.lib.case_abi_features() & A.FEAT_POINTER_DECODE))
+
+
+def additive_key_exp(uh):
+    """uh f32 [..., H] (the key projection Wk k) -> bf16 e^{2 uh}, the form ops.pointer_attend_decode streams (no autograd)."""
+    uh = uh.detach()
+    uh = uh if uh.is_contiguous() else uh.contiguous()
+    eu = torch.empty(uh.shape, dtype=torch.bfloat16, device=uh.device)
+    A.call("case_additive_key_exp", _ptr(uh), _ptr(eu), uh.numel(), _stream())
+    return eu
+
+
+def pointer_attend_decode(wq, eu, v, value, col_valid=None, row_valid=None, prior=None):
+    """wq f32 [B, H]; eu / value bf16 [B, S, H]; v f32 [H]; masks bool; prior f32 [B, S] -> (ctx bf16 [B, H], p f32 [B, S], copy f32 [B, S] | None)."""
+    B, S, H = value.shape
+    wq = wq.reshape(B, H)
+    wq = wq if wq.is_contiguous() else wq.contiguous()
+    ctx = torch.empty(B, H, dtype=torch.bfloat16, device=value.device)
+    p = torch.empty(B, S, dtype=torch.float32, device=value.device)
+    copy = torch.empty_like(p) if prior is not None else None
+    if prior is not None:
+        prior = prior.reshape(B, S).float()
+        prior = prior if prior.is_contiguous() else prior.contiguous()
+    A.call("case_pointer_attend_decode", _ptr(wq), _ptr(eu), _ptr(v), _ptr(value), _ptr(_u8(col_valid)), _ptr(_u8(row_valid)), _ptr(prior),
+           _ptr(ctx), _ptr(p), _ptr(copy), B, S, H, _stream())
+    return ctx, p, copy
+
+
 class SortedSource(object):
     """A source map [B, S] with its device-sorted (token, position) keys, made once per batch and shared by every
     pointer scatter of that batch (one per training step; one per generated token in greedy decoding)."""

@@ -44,7 +44,7 @@ enum {
  * written against (case_rg_amd/_abi.py refuses any other library).  Bumped with every struct or signature change:
  *   100 round 1 | 200 round 2 (case_gemm_dw_bias, decode, optimizer) | 300 round 3 (CaseOptTensor 56 -> 64 bytes, K16 / K17)
  *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs)
- *   500 round 5 (K21 case_attention_decode_mqa, ...). */
+ *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode). */
 #define CASE_ABI_VERSION 500
 int case_version(void);
 /* what the build contains, as a bit mask */
@@ -59,7 +59,8 @@ enum {
   CASE_FEAT_RESERVED_CUS = 1u << 7,    /* case_set_reserved_cus */
   CASE_FEAT_GEMM_DW_SLABS = 1u << 8,   /* case_gemm_dw_slabs: atomics-free, run-to-run deterministic split-K weight gradients */
   CASE_FEAT_DECODER_CHAIN = 1u << 9,   /* K20 case_decoder_chain */
-  CASE_FEAT_ATTN_DECODE_MQA = 1u << 10 /* K21 case_attention_decode_mqa */
+  CASE_FEAT_ATTN_DECODE_MQA = 1u << 10, /* K21 case_attention_decode_mqa */
+  CASE_FEAT_POINTER_DECODE = 1u << 11   /* K22 case_pointer_attend_decode / case_additive_key_exp */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -272,7 +273,7 @@ int case_attention_decode(const CaseAttnDesc* d, const void* q, const void* k, c
  * ranges per item (case_attention_decode_mqa_splits picks one for (B, S); > 1 needs a workspace of case_attention_decode_mqa_workspace
  * bytes, 16-byte aligned).  bf16, 8 heads, width 512 only. */
 int64_t case_attention_decode_mqa_workspace(int64_t B, int64_t S, int32_t nsplit);
-int32_t case_attention_decode_mqa_splits(int64_t B, int64_t S);
+int case_attention_decode_mqa_splits(int64_t B, int64_t S);
 int case_attention_decode_mqa(const void* qp, const void* mem, const uint8_t* key_valid, void* out, int64_t B, int64_t S, int64_t ldo,
                               int32_t nsplit, void* workspace, int64_t workspace_bytes, case_stream_t stream);
 int case_attention_bwd_supported(int64_t head_dim);
@@ -386,6 +387,17 @@ int case_additive_scores_bwd(const float* ds, const float* wq, const void* uh, c
                              float* d_uh, float* d_v, int64_t B, int64_t T, int64_t S, int64_t H, int32_t dtype,
                              case_stream_t stream);
 
+/* K22 (round 5), the greedy step's additive attention in one launch (common/BilinearAttention.py:31-59 at T = 1, CaSE/Model.py:79-82):
+ *   s_j = v . tanh(wq + uh_j),  p = softmax_j(s | col_valid) (0 where masked, all 0 for an invalid target row),  ctx = sum_j p_j value_j,
+ *   copy_j = p_j prior_j / (1e-8 + sum_j p_j prior_j)   (when prior is given)
+ * with tanh(a + b) = 1 - 2 / (e^{2a} e^{2b} + 1) and eu = e^{2 uh} CACHED across the steps (case_additive_key_exp: f32 uh -> bf16 eu, both
+ * exponents clamped at +-43): one reciprocal per element instead of an exponential and a reciprocal.  wq [B, H] f32 (query projection incl.
+ * bias), eu / value [B, S, H] bf16, v [H] f32, col_valid [B, S] / row_valid [B] bytes (nullable), prior [B, S] f32 (nullable, with copy);
+ * outputs ctx [B, H] bf16, p [B, S] f32, copy [B, S] f32.  One workgroup per item; H = 512, S <= 28000; CASE_E_UNSUPPORTED otherwise. */
+int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_stream_t stream);
+int case_pointer_attend_decode(const float* wq, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
+                               const uint8_t* row_valid, const float* prior, void* ctx, float* p, float* copy, int64_t B, int64_t S, int64_t H,
+                               case_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * K11 copy / pointer distribution: CaSE/Model.py:38-48 with common/Utils.py:344-355
  *   dist[b, t, src[b, s]] += w[b, t, s]        (scatter-add instead of the dense one-hot bmm)

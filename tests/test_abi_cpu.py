@@ -31,7 +31,7 @@ def test_ctypes_table_matches_header():
     from case_rg_amd import _abi
     other = {"case_version", "case_last_error", "case_gemm_tile_for", "case_optim_chunk_elems", "case_abi_features", "case_get_reserved_cus",
              "case_sizeof_opt_tensor", "case_workspace_bytes", "case_attention_bwd_scratch_floats", "case_encoder_chain_packed_bytes",
-             "case_gemm_dw_slab_bytes"}
+             "case_gemm_dw_slab_bytes", "case_attention_decode_mqa_workspace", "case_attention_decode_mqa_splits"}
     assert set(_abi.SIGNATURES) | other == _declared()
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for name, args in _abi.SIGNATURES.items():

@@ -168,9 +168,10 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     import case_rg_amd
     from case_rg_amd import ops
     bars = GREEDY_BARS[mode]
-    old_pairs, old_absorb = ops.DECODE_MIN_PAIRS, (ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS)
+    old_pairs, old_absorb = ops.DECODE_MIN_PAIRS, (ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS, ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH)
     ops.DECODE_MIN_PAIRS = 1  # 2 sequences x 8 heads here; bench.py's batch 256 is above the default threshold by itself
     ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS = ("auto", 512) if mode == "bf16_absorb" else ("off", 1 << 30)
+    ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH = ("auto", 1) if mode == "bf16_absorb" else ("off", 1 << 30)  # K22 rides in the same mode
     try:
         with _Mode(mode) as m:
             ns = case_rg_amd.namespace()
@@ -179,11 +180,12 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
             torch.cuda.synchronize()
     finally:
         ops.DECODE_MIN_PAIRS = old_pairs
-        ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS = old_absorb
+        ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS, ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH = old_absorb
     if mode == "bf16_absorb":
         assert m.calls.get("case_attention_decode_mqa", 0) >= 4 * 14, "K21 did not run in every layer-step of the passage stack"
+        assert m.calls.get("case_pointer_attend_decode", 0) >= 2 * 14, "K22 did not run for both memories in every step"
     else:
-        assert m.calls.get("case_attention_decode_mqa", 0) == 0
+        assert m.calls.get("case_attention_decode_mqa", 0) == 0 and m.calls.get("case_pointer_attend_decode", 0) == 0
     golden = load_golden(name)
     assert set(rec) == set(golden)
     for k in ("in_query", "in_passage", "in_source_map"):
@@ -226,7 +228,7 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     if mode in ("bf16_auto", "bf16_absorb"):
         assert m.calls.get("case_attention_decode", 0) > 0, "attn_decode64_kernel did not run"
         assert 64 in m.tiles, "no GEMM ran on the 64x64 small-problem tiling"
-        assert m.calls.get("additive_decode_row", 0) > 0, "the T = 1 additive-attention kernel did not run"
+        assert m.calls.get("additive_decode_row", 0) > 0 or mode == "bf16_absorb", "the T = 1 additive-attention kernel did not run"
         assert m.calls.get("case_copy_scatter_sorted_fwd", 0) > 0, "the sorted pointer scatter did not run"
 
 
