@@ -40,9 +40,13 @@ class CaSETransformerSeqDecoder(PointerDecoderCore):
         feat = ops.layer_norm(answer_rep, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return ops.dropout(feat.unsqueeze(1).expand(-1, T, -1).contiguous(), 0.1, self.training)
 
-    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
+    def _head_parts(self, dec_in, x, feat):
         dec_out = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        gen = self._generate(torch.cat([dec_in, dec_out, feat], dim=-1), self.gen[1].p)
+        return dec_out, torch.cat([dec_in, dec_out, feat], dim=-1)
+
+    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
+        dec_out, gen_in = self._head_parts(dec_in, x, feat)
+        gen = self._generate(gen_in, self.gen[1].p)
         d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
         return dec_out, gen, ((d1, d2) if self.training else ops.add(d1, d2))
 

@@ -29,9 +29,13 @@ class MasqueTransformerSeqDecoder(PointerDecoderCore):
                            memory_weights, source_map)
         return d1 + d2
 
-    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
+    def _head_parts(self, dec_in, x, feat):
         dec_out = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        gen = self._generate(torch.cat([dec_in, dec_out], dim=-1), 0.0)
+        return dec_out, torch.cat([dec_in, dec_out], dim=-1)
+
+    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
+        dec_out, gen_in = self._head_parts(dec_in, x, feat)
+        gen = self._generate(gen_in, 0.0)
         d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
         return dec_out, gen, ops.add(d1, d2)
 

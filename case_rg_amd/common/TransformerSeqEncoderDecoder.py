@@ -172,6 +172,7 @@ class PointerDecoderCore(nn.Module):
         picked = []
         finished = None if self.eos_id is None else torch.zeros(B, dtype=torch.bool, device=dev)
         capturing = torch.cuda.is_current_stream_capturing()  # a captured pass cannot branch on device data: fixed T steps
+        fused_head = (not self.training and hasattr(self, "_head_parts") and ops.pointer_head_supported(source_map, self.tgt_vocab_size, len(mems)))
         for t in range(max_target_length):
             tok_valid = ids.ne(0)
             hist_valid[:, t] = tok_valid[:, 0]
@@ -190,8 +191,12 @@ class PointerDecoderCore(nn.Module):
                         p = p / (1e-8 + p.sum(dim=-1, keepdim=True))
                 ctxs.append(ctx)
                 copies.append(p)
-            dec_out, gen, dist = self._head(dec_in, x, ctxs, copies, feat, source_map)
-            ids = ops.row_argmax(dist[:, -1])[0].unsqueeze(1)
+            if fused_head:  # K23: vocabulary softmax, mixing, pointer scatter and argmax in one launch
+                dec_out, gen_in = self._head_parts(dec_in, x, feat)
+                gen, dist, ids = self._head_decode(dec_out, gen_in, ctxs, copies, source_map)
+            else:
+                dec_out, gen, dist = self._head(dec_in, x, ctxs, copies, feat, source_map)
+                ids = ops.row_argmax(dist[:, -1])[0].unsqueeze(1)
             if finished is not None:
                 ids = ids.masked_fill(finished.unsqueeze(1), 0)  # PAD behind a finished answer (to_sentence stops at EOS anyway)
                 finished = finished | ids[:, 0].eq(self.eos_id)
@@ -204,6 +209,16 @@ class PointerDecoderCore(nn.Module):
         if answer.size(1) < max_target_length:
             answer = torch.nn.functional.pad(answer, (0, max_target_length - answer.size(1)))
         return dec_out, gen, dist, answer
+
+    def _head_decode(self, dec_out, gen_in, ctxs, copies, source_map):
+        """The head of one greedy step through K23 (ops.pointer_head_decode): the two generator Linears and the mixing Linear, then ONE
+        launch for softmax over V, softmax over the mixing logits, p0 x gen + the pointer scatter, and the argmax."""
+        B, V = dec_out.shape[0], self.tgt_vocab_size
+        h = ops.linear(gen_in, self.gen[0].weight, self.gen[0].bias)
+        logits = ops.linear(h, self.gen[-2].weight, None, out_dtype=torch.float32)
+        mix_logits = ops.linear(torch.cat([dec_out] + ctxs, dim=-1), self.mix.weight, self.mix.bias, out_dtype=torch.float32)
+        gen, dist, ids = ops.pointer_head_decode(logits.reshape(B, V), mix_logits.reshape(B, -1), source_map, [c.reshape(B, -1) for c in copies])
+        return gen.view(B, 1, V), dist.view(B, 1, V), ids.unsqueeze(1)
 
     def _generate(self, gen_in, hidden_drop):
         """gen = softmax(W_v (drop(W_h x + b)))  -- f32 logits and probabilities (K10)."""
@@ -245,9 +260,13 @@ class TransformerSeqDecoder(PointerDecoderCore):
         self.gen = nn.Sequential(nn.Linear(2 * H, H), nn.Linear(H, tgt_vocab_size, bias=False), nn.Softmax(dim=-1))
         self.mix = nn.Linear(H + num_memories * H, num_memories + 1)
 
-    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
+    def _head_parts(self, dec_in, x, feat):
         dec_out = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        gen = self._generate(torch.cat([dec_in, dec_out], dim=-1), 0.0)
+        return dec_out, torch.cat([dec_in, dec_out], dim=-1)
+
+    def _head(self, dec_in, x, ctxs, copies, feat, source_map):
+        dec_out, gen_in = self._head_parts(dec_in, x, feat)
+        gen = self._generate(gen_in, 0.0)
         d1, d2 = self._mix(dec_out, ctxs, gen, copies, source_map)
         return dec_out, gen, d1 + d2
 

@@ -417,6 +417,146 @@ __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
   }
 }
 
+// ---- K23 (round 5): the greedy step's pointer-generator head in one launch ----------------------------------------------------------
+// gen = softmax(logits); pm = softmax(mix logits); dist = pm_0 gen + scatter(pm_k copy_k over the sorted source keys); id = argmax dist
+// (CaSE/Model.py:34-48, :112-117, common/Utils.py:156-168 with the lowest index on ties).  One workgroup per answer row keeps the whole
+// vocabulary row in LDS (V <= 36 000 floats): the five passes over the [B, V] matrix of the separate launches (softmax, p0 x gen,
+// zero-fill + scatter, sum, argmax: ~0.2 ms per step at B 256 x V 30 522) become one read of the logits and one write of each output.
+constexpr int PH_THREADS = 1024, PH_MAX_MEM = 4;
+struct HeadArgs {
+  const float* logits;      // [B, V]
+  const float* mix_logits;  // [B, 1 + nmem]
+  const uint32_t* keys;     // [B, S] sorted (token << 15 | position), 0xFFFFFFFF = no token
+  const float* copy[PH_MAX_MEM];  // copy_k [B, len_k]: pointer weights of memory k (positions offset by the lengths before it)
+  int64_t len[PH_MAX_MEM];
+  float* gen;               // [B, V] or null
+  float* dist;              // [B, V]
+  int64_t* ids;             // [B]
+  float* top;               // [B] or null: dist[id]
+  int64_t V, S;
+  int nmem;
+};
+
+__global__ __launch_bounds__(PH_THREADS) void pointer_head_decode_kernel(const HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ph_smem[];
+  float* row = ph_smem;                                  // [V]
+  uint32_t* tk = reinterpret_cast<uint32_t*>(ph_smem + ((a.V + 3) & ~(int64_t)3));  // [PH_THREADS + 1]
+  float* tv = reinterpret_cast<float*>(tk + PH_THREADS + 4);                       // [PH_THREADS]
+  float* red = tv + PH_THREADS;                                                    // [64] reduction scratch
+  __shared__ int64_t best_i[16];
+  __shared__ float best_v[16];
+  const int64_t b = blockIdx.x, V = a.V;
+  const int tid = threadIdx.x;
+  // the mixing probabilities (1 + nmem <= 5 values; every thread computes them)
+  float pm[1 + PH_MAX_MEM];
+  {
+    float mm = -INFINITY, ss = 0.f;
+#pragma unroll
+    for (int k = 0; k <= PH_MAX_MEM; ++k) pm[k] = k <= a.nmem ? a.mix_logits[b * (a.nmem + 1) + k] : -INFINITY;
+#pragma unroll
+    for (int k = 0; k <= PH_MAX_MEM; ++k) mm = fmaxf(mm, pm[k]);
+#pragma unroll
+    for (int k = 0; k <= PH_MAX_MEM; ++k) {
+      pm[k] = __expf(pm[k] - mm);  // exp(-inf) = 0 for the slots behind nmem
+      ss += pm[k];
+    }
+#pragma unroll
+    for (int k = 0; k <= PH_MAX_MEM; ++k) pm[k] /= ss;
+  }
+  const float* lg = a.logits + b * V;
+  float mx = -INFINITY;
+  for (int64_t i = tid; i < V; i += PH_THREADS) {
+    const float x = lg[i];
+    row[i] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = block_max(mx, red);
+  float sum = 0.f;
+  for (int64_t i = tid; i < V; i += PH_THREADS) {
+    const float e = __expf(row[i] - mx);
+    row[i] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, red);
+  const float inv = 1.f / sum;
+  for (int64_t i = tid; i < V; i += PH_THREADS) {
+    const float g = row[i] * inv;
+    if (a.gen) a.gen[b * V + i] = g;
+    row[i] = pm[0] * g;
+  }
+  __syncthreads();
+  // pointer mass: the keys of a row are sorted by token, so a token's positions form runs; the last lane of a run inside a chunk sums it
+  // (fixed order) and adds it to the row -- a token's run in a later chunk is added by a later iteration: no atomics, scheduling-free
+  const uint32_t* k = a.keys + b * a.S;
+  for (int64_t base = 0; base < a.S; base += PH_THREADS) {
+    const int64_t i = base + tid;
+    const uint32_t key = i < a.S ? k[i] : 0xFFFFFFFFu;
+    const bool valid = key != 0xFFFFFFFFu;
+    float w = 0.f;
+    if (valid) {
+      int64_t pos = key & 0x7FFFu;
+      bool done = false;
+#pragma unroll
+      for (int m = 0; m < PH_MAX_MEM; ++m) {  // (compile-time m: pm[] stays in registers)
+        if (m < a.nmem && !done) {
+          if (pos < a.len[m]) {
+            w = pm[m + 1] * a.copy[m][b * a.len[m] + pos];
+            done = true;
+          }
+          pos -= a.len[m];
+        }
+      }
+    }
+    tk[tid] = valid ? (key >> 15) : 0xFFFFFFFFu;
+    tv[tid] = w;
+    if (tid == 0) tk[PH_THREADS] = 0xFFFFFFFEu;
+    __syncthreads();
+    const uint32_t tok = tk[tid];
+    if (valid && tok != tk[tid + 1]) {
+      int j = tid;
+      while (j > 0 && tk[j - 1] == tok) --j;
+      float s2 = 0.f;
+      for (; j <= tid; ++j) s2 += tv[j];
+      if (s2 != 0.f && tok < (uint32_t)V) row[tok] += s2;
+    }
+    __syncthreads();
+  }
+  // outputs: the distribution row and its argmax (lowest index on ties)
+  float bv = -INFINITY;
+  int64_t bi = V;
+  for (int64_t i = tid; i < V; i += PH_THREADS) {
+    const float x = row[i];
+    a.dist[b * V + i] = x;
+    if (x > bv) {  // indices ascend within a thread: the first maximum is kept
+      bv = x;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    best_v[tid >> 6] = bv;
+    best_i[tid >> 6] = bi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < PH_THREADS / 64; ++w)
+      if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) {
+        bv = best_v[w];
+        bi = best_i[w];
+      }
+    a.ids[b] = bi < V ? bi : 0;
+    if (a.top) a.top[b] = bv;
+  }
+}
+
 // ---- K11 ---------------------------------------------------------------------------------------
 __global__ void copy_scatter_fwd_kernel(const int64_t* __restrict__ src, const float* __restrict__ w,
                                         float* __restrict__ dist, int64_t B, int64_t Tn, int64_t S, int64_t V) {
@@ -651,6 +791,45 @@ extern "C" int case_pointer_attend_decode(const float* wq, const void* eu, const
                      reinterpret_cast<const bf16_t*>(eu), v, reinterpret_cast<const bf16_t*>(value), col_valid, row_valid, prior,
                      reinterpret_cast<bf16_t*>(ctx), p, copy, S);
   return case_check_launch("case_pointer_attend_decode");
+}
+
+extern "C" int case_pointer_head_decode(const float* logits, const float* mix_logits, const uint32_t* keys, const float* const* copies,
+                                        const int64_t* lens, int32_t nmem, float* gen, float* dist, int64_t* ids, float* top, int64_t B, int64_t V,
+                                        int64_t S, case_stream_t stream) {
+  CASE_REQUIRE(logits && mix_logits && keys && copies && lens && dist && ids && B > 0 && V > 0 && S > 0 && nmem >= 1 && B < (1ll << 31),
+               "case_pointer_head_decode: bad argument");
+  if (nmem > PH_MAX_MEM || V > 36000 || S > 32768)
+    return case_set_error(CASE_E_UNSUPPORTED, "case_pointer_head_decode: built for <= %d memories, V <= 36000, S <= 32768 (run the softmax / "
+                                              "scatter / argmax launches)", PH_MAX_MEM);
+  HeadArgs a;
+  a.logits = logits;
+  a.mix_logits = mix_logits;
+  a.keys = keys;
+  int64_t total = 0;
+  for (int m = 0; m < PH_MAX_MEM; ++m) {
+    a.copy[m] = m < nmem ? copies[m] : nullptr;
+    a.len[m] = m < nmem ? lens[m] : 0;
+    total += a.len[m];
+    CASE_REQUIRE(m >= nmem || (copies[m] && lens[m] > 0), "case_pointer_head_decode: null copy weights");
+  }
+  CASE_REQUIRE(total == S, "case_pointer_head_decode: the memories hold %lld positions, the source map %lld", (long long)total, (long long)S);
+  a.gen = gen;
+  a.dist = dist;
+  a.ids = ids;
+  a.top = top;
+  a.V = V;
+  a.S = S;
+  a.nmem = nmem;
+  const size_t lds = (size_t)(((V + 3) & ~(int64_t)3) + (PH_THREADS + 4) + PH_THREADS + 64) * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pointer_head_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) !=
+        hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_pointer_head_decode: cannot reserve LDS");
+    attr = true;
+  }
+  hipLaunchKernelGGL(pointer_head_decode_kernel, dim3((unsigned)B), dim3(PH_THREADS), lds, (hipStream_t)stream, a);
+  return case_check_launch("case_pointer_head_decode");
 }
 
 extern "C" int case_copy_scatter_fwd(const int64_t* src, const float* w, float* dist, int64_t B, int64_t T, int64_t S,

@@ -5,6 +5,7 @@ arithmetic pass over an activation is a kernel of libcase_hip.so launched throug
 stream.  There is no eager fallback: tensors must live on a ROCm device.
 """
 import math
+import ctypes as C
 import os
 import weakref
 
@@ -1679,6 +1680,34 @@ def pointer_attend_decode(wq, eu, v, value, col_valid=None, row_valid=None, prio
     A.call("case_pointer_attend_decode", _ptr(wq), _ptr(eu), _ptr(v), _ptr(value), _ptr(_u8(col_valid)), _ptr(_u8(row_valid)), _ptr(prior),
            _ptr(ctx), _ptr(p), _ptr(copy), B, S, H, _stream())
     return ctx, p, copy
+
+
+# K23: the greedy step's head (vocabulary softmax, mixing softmax, p0 x gen + pointer scatter, argmax) as one launch with the vocabulary
+# row in LDS.  "auto": a device-sorted source map, V <= 36000, <= 4 memories, inference; "off": the separate launches.
+POINTER_HEAD = os.environ.get("CASE_POINTER_HEAD", "auto")
+
+
+def pointer_head_supported(source_map, V, nmem):
+    return (POINTER_HEAD != "off" and isinstance(source_map, SortedSource) and V <= 36000 and 1 <= nmem <= 4
+            and bool(A.lib.case_abi_features() & A.FEAT_POINTER_HEAD))
+
+
+def pointer_head_decode(logits, mix_logits, source_map, copies, want_gen=True):
+    """logits f32 [B, V]; mix_logits f32 [B, 1 + nmem]; source_map a SortedSource over the concatenated memories; copies: list of f32
+    [B, len_k] pointer weights -> (gen [B, V] | None, dist [B, V], ids [B] int64) (no autograd: inference)."""
+    B, V = logits.shape
+    logits = logits if logits.is_contiguous() else logits.contiguous()
+    mix_logits = mix_logits.float().contiguous()
+    cs = [c.float().contiguous() for c in copies]
+    n = len(cs)
+    ptrs = (C.c_void_p * n)(*[c.data_ptr() for c in cs])
+    lens = (C.c_int64 * n)(*[c.shape[1] for c in cs])
+    gen = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_gen else None
+    dist = torch.empty(B, V, dtype=torch.float32, device=logits.device)
+    ids = torch.empty(B, dtype=torch.int64, device=logits.device)
+    A.call("case_pointer_head_decode", _ptr(logits), _ptr(mix_logits), _ptr(source_map.keys), C.cast(ptrs, C.c_void_p), C.cast(lens, C.c_void_p), n,
+           _ptr(gen), _ptr(dist), _ptr(ids), None, B, V, source_map.keys.shape[1], _stream())
+    return gen, dist, ids
 
 
 class SortedSource(object):

@@ -44,7 +44,7 @@ enum {
  * written against (case_rg_amd/_abi.py refuses any other library).  Bumped with every struct or signature change:
  *   100 round 1 | 200 round 2 (case_gemm_dw_bias, decode, optimizer) | 300 round 3 (CaseOptTensor 56 -> 64 bytes, K16 / K17)
  *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs)
- *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode). */
+ *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode, K23 case_pointer_head_decode). */
 #define CASE_ABI_VERSION 500
 int case_version(void);
 /* what the build contains, as a bit mask */
@@ -60,7 +60,8 @@ enum {
   CASE_FEAT_GEMM_DW_SLABS = 1u << 8,   /* case_gemm_dw_slabs: atomics-free, run-to-run deterministic split-K weight gradients */
   CASE_FEAT_DECODER_CHAIN = 1u << 9,   /* K20 case_decoder_chain */
   CASE_FEAT_ATTN_DECODE_MQA = 1u << 10, /* K21 case_attention_decode_mqa */
-  CASE_FEAT_POINTER_DECODE = 1u << 11   /* K22 case_pointer_attend_decode / case_additive_key_exp */
+  CASE_FEAT_POINTER_DECODE = 1u << 11,  /* K22 case_pointer_attend_decode / case_additive_key_exp */
+  CASE_FEAT_POINTER_HEAD = 1u << 12     /* K23 case_pointer_head_decode */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -395,6 +396,16 @@ int case_additive_scores_bwd(const float* ds, const float* wq, const void* uh, c
  * bias), eu / value [B, S, H] bf16, v [H] f32, col_valid [B, S] / row_valid [B] bytes (nullable), prior [B, S] f32 (nullable, with copy);
  * outputs ctx [B, H] bf16, p [B, S] f32, copy [B, S] f32.  One workgroup per item; H = 512, S <= 28000; CASE_E_UNSUPPORTED otherwise. */
 int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_stream_t stream);
+/* K23 (round 5), the greedy step's pointer-generator head in one launch (CaSE/Model.py:34-48, :112-117; Masque/Model.py:29-44; argmax as
+ * common/Utils.py:156-168, lowest index on ties):  gen = softmax(logits);  pm = softmax(mix_logits);
+ *   dist[b, :] = pm[b, 0] gen[b, :] + sum_k scatter(pm[b, 1 + k] copies[k][b, :] over the source tokens);  ids[b] = argmax dist[b, :].
+ * logits / gen / dist [B, V] f32 (gen nullable), mix_logits [B, 1 + nmem] f32, keys [B, S] the sorted (token << 15 | position) keys of
+ * case_source_sort over the concatenated source map, copies = nmem device pointers (host array) to [B, lens[k]] f32 weights, sum lens = S,
+ * ids [B] int64, top [B] f32 (nullable) = dist[b, ids[b]].  One workgroup per row, the vocabulary row in LDS: V <= 36000, nmem <= 4,
+ * S <= 32768; CASE_E_UNSUPPORTED otherwise (run case_softmax_fwd / case_copy_scatter_sorted_fwd / case_row_argmax). */
+int case_pointer_head_decode(const float* logits, const float* mix_logits, const uint32_t* keys, const float* const* copies,
+                             const int64_t* lens, int32_t nmem, float* gen, float* dist, int64_t* ids, float* top, int64_t B, int64_t V,
+                             int64_t S, case_stream_t stream);
 int case_pointer_attend_decode(const float* wq, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
                                const uint8_t* row_valid, const float* prior, void* ctx, float* p, float* copy, int64_t B, int64_t S, int64_t H,
                                case_stream_t stream);

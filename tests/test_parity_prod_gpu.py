@@ -169,6 +169,8 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     from case_rg_amd import ops
     bars = GREEDY_BARS[mode]
     old_pairs, old_absorb = ops.DECODE_MIN_PAIRS, (ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS, ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH)
+    old_head = ops.POINTER_HEAD
+    ops.POINTER_HEAD = "off" if mode == "bf16_auto" else "auto"  # K23 (fused head) runs in fp32 and bf16_absorb; bf16_auto keeps the separate launches covered
     ops.DECODE_MIN_PAIRS = 1  # 2 sequences x 8 heads here; bench.py's batch 256 is above the default threshold by itself
     ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS = ("auto", 512) if mode == "bf16_absorb" else ("off", 1 << 30)
     ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH = ("auto", 1) if mode == "bf16_absorb" else ("off", 1 << 30)  # K22 rides in the same mode
@@ -181,6 +183,8 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     finally:
         ops.DECODE_MIN_PAIRS = old_pairs
         ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS, ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH = old_absorb
+        ops.POINTER_HEAD = old_head
+    assert (m.calls.get("case_pointer_head_decode", 0) >= 14) == (mode != "bf16_auto"), "K23 must run in fp32 / bf16_absorb and only there"
     if mode == "bf16_absorb":
         assert m.calls.get("case_attention_decode_mqa", 0) >= 4 * 14, "K21 did not run in every layer-step of the passage stack"
         assert m.calls.get("case_pointer_attend_decode", 0) >= 2 * 14, "K22 did not run for both memories in every step"
@@ -229,7 +233,7 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
         assert m.calls.get("case_attention_decode", 0) > 0, "attn_decode64_kernel did not run"
         assert 64 in m.tiles, "no GEMM ran on the 64x64 small-problem tiling"
         assert m.calls.get("additive_decode_row", 0) > 0 or mode == "bf16_absorb", "the T = 1 additive-attention kernel did not run"
-        assert m.calls.get("case_copy_scatter_sorted_fwd", 0) > 0, "the sorted pointer scatter did not run"
+        assert m.calls.get("case_copy_scatter_sorted_fwd", 0) > 0 or mode == "bf16_absorb", "the sorted pointer scatter did not run"
 
 
 @pytest.mark.parametrize("model", ["masque", "case", "masque_p10", "case_p10"])

@@ -81,3 +81,41 @@ def test_attend_decode_agrees_with_the_four_launch_form():
         assert (c1 - c0).abs().max().item() <= 3e-2 * c0.abs().max().item()
     finally:
         case_rg_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("B,V,lens", [(6, 30522, (64, 3840)), (3, 150, (5, 9)), (130, 1000, (40,)), (2, 33000, (7, 8, 9, 10))])
+def test_pointer_head_decode_matches_the_separate_launches(B, V, lens):
+    """K23 against softmax -> p0 x gen -> sorted scatter -> add -> argmax (the launches it replaces), same inputs: gen and dist to f32
+    rounding, the ids exactly (incl. a planted tie: the lowest index wins)."""
+    from case_rg_amd import ops
+    g = torch.Generator().manual_seed(V)
+    logits = (torch.randn(B, V, generator=g) * 3).to(DEV)
+    mix = torch.randn(B, 1 + len(lens), generator=g).to(DEV)
+    S = sum(lens)
+    src = torch.randint(0, V, (B, S), generator=g).to(DEV)
+    src[0, : S // 2] = src[0, 0]          # a long run of one token
+    src[1 % B, -1] = V + 5                # an out-of-vocabulary id: no mass
+    copies = [torch.rand(B, n, generator=g).to(DEV) for n in lens]
+    copies[0][0, 0] = 0.0
+    sm = ops.SortedSource(src, V)
+    gen, dist, ids = ops.pointer_head_decode(logits, mix, sm, copies)
+    gen0 = ops.masked_softmax(logits.view(B, 1, V))
+    pm = torch.softmax(mix, -1)
+    ptr = torch.cat([pm[:, k + 1:k + 2] * c for k, c in enumerate(copies)], dim=-1).view(B, 1, S)
+    dist0 = pm[:, 0:1].unsqueeze(-1) * gen0 + ops.copy_scatter(sm, ptr, V)
+    assert torch.allclose(gen, gen0.view(B, V), rtol=2e-5, atol=1e-9)
+    assert torch.allclose(dist, dist0.view(B, V), rtol=3e-5, atol=1e-8)
+    assert torch.equal(ids, ops.row_argmax(dist)[0]), "argmax of the fused head's own distribution"
+    top2 = dist0.view(B, V).topk(2, dim=-1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 1e-6 * top2[:, 0]
+    assert torch.equal(ids[decisive], dist0.view(B, V).argmax(-1)[decisive])
+    # a tie: two equal logits far above the rest, no pointer mass on either -> the lower index
+    logits2 = torch.full((B, V), -5.0, device=DEV)
+    logits2[:, 11] = 9.0
+    logits2[:, 7] = 9.0
+    src2 = torch.full((B, S), 3, device=DEV)
+    _, dist2, ids2 = ops.pointer_head_decode(logits2, mix, ops.SortedSource(src2, V), copies, want_gen=False)
+    assert ids2.tolist() == [3 if float(dist2[b, 3]) > float(dist2[b, 7]) else 7 for b in range(B)]
+    # bit-identical from launch to launch
+    gen3, dist3, ids3 = ops.pointer_head_decode(logits, mix, sm, copies)
+    assert torch.equal(dist, dist3) and torch.equal(ids, ids3) and torch.equal(gen, gen3)
