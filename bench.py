@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-north-star", action="store_true", help="skip the encoder-forward point appended to the default line")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the BASELINE workload keeps dropout on")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
-    ap.add_argument("--mode", default="train", choices=["train", "decode", "encoder", "cfg5"],
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "encoder", "cfg5", "refdefault"],
                     help="train: tokens/s of the training step (default, BASELINE cfg 2); decode: greedy answers/s (cfg 4); "
                          "encoder: the north-star point, TransformerSeqEncoder forward at batch x passages x passage-len; "
                          "cfg5: the long-context training step (d_model 768, 40 passages x 512 tokens, batch 4 per GPU) with the "
@@ -534,6 +534,14 @@ def main():
     if a.mode == "cfg5":  # BASELINE cfg 5: 40 passages x 512 tokens, d_model 768, 4 items per GPU; the reference's 3 encoder layers
         a.hidden, a.passages, a.passage_len, a.enc_layers = 768, 40, 512, 3
         a.batch = 4 if a.batch == 32 else a.batch
+    if a.mode == "refdefault":
+        # the reference's OWN default geometry (CaSE/Run.py:72-78: hidden 256, batch 16 per GPU; Prepare_dataset.py:13-17: query 60, passage
+        # 100 tokens, 10 passages, answers of 40; CaSE/Model.py's 3 encoder layers): head_dim 32 in the encoder / H-wide blocks / decoder and
+        # 160 in the 5H blocks -- what "drops into Run.py unchanged" lands on.  Reported like the training line; no roofline object.
+        a.hidden, a.passages, a.passage_len, a.query_len, a.answer_len, a.enc_layers = 256, 10, 100, 60, 40, 3
+        a.batch = 16 if a.batch == 32 else a.batch
+        a.no_roofline, a.no_north_star, a.no_cpu_baseline, a.mode = True, True, True, "train"
+        a.refdefault = True
     if a.mode == "decode":
         decode_main(a, device, world, rank)
         if world > 1:
@@ -601,6 +609,8 @@ def main():
                                 "gradient_mb": round(sum(b["flat"].numel() for b in trainer.sync.buckets) * 4 / 2 ** 20, 1),
                                 "wire_dtype": "bf16" if trainer.sync.comm_dtype is not None else "f32",
                                 "reserved_cus": int(getattr(trainer.sync, "reserved_cus", 0)), "reserved_while": "first all-reduce of the step .. finish()"}
+    if getattr(a, "refdefault", False):
+        out["metric"] += ", the reference's default geometry (hidden 256, 10 x 100-token passages, batch 16)"
     if a.mode == "cfg5":
         out["metric"] += ", cfg 5 long context"
         if rank == 0 and not a.no_roofline:
