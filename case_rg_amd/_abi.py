@@ -16,7 +16,7 @@ ABI_VERSION = 500  # include/case_hip.h CASE_ABI_VERSION this binding was writte
 F32, BF16 = 0, 1
 WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
 (FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
- FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA, FEAT_POINTER_DECODE, FEAT_POINTER_HEAD) = (1 << i for i in range(13))
+ FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA, FEAT_POINTER_DECODE, FEAT_POINTER_HEAD, FEAT_GEMM_LN) = (1 << i for i in range(14))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -116,6 +116,7 @@ SIGNATURES = {
     "case_additive_key_exp": [ptr, ptr, i64, ptr],
     "case_pointer_attend_decode": [ptr] * 10 + [i64, i64, i64, ptr],
     "case_pointer_head_decode": [ptr] * 5 + [i32] + [ptr] * 4 + [i64, i64, i64, ptr],
+    "case_gemm_ln": [C.POINTER(GemmDesc), ptr, ptr, ptr, f32, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
     "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
 }

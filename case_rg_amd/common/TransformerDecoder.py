@@ -57,17 +57,22 @@ class TransformerDecoderLayer(nn.Module):
         prefix (CaSE/Model.py:94-123) because of the causal mask: earlier positions never see later ones."""
         E = self.self_attn.embed_dim
         sa, ca = self.self_attn, self.multihead_attn
-        x = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        n1, n2, n3 = [(n.weight, n.bias, n.eps) for n in (self.norm1, self.norm2, self.norm3)]
+        # round 5: each LayerNorm rides in the prologue of the projection it feeds (ops.ln_linear -> case_gemm_ln) where that applies
+        # (bf16, width 512, a multiple of 64 sequences); the normalised rows come back as the residual of the layer's next GEMM
+        fused = ops.ln_gemm_supported(x, E) and self.linear1.out_features % 64 == 0 and self.activation in ("gelu", "relu")
+        qkv, x = ops.ln_linear(x, n1, sa.in_proj_weight, sa.in_proj_bias)
         self_kv[:, t] = qkv[:, 0, E:]
         ctx = ops.attention(qkv, self_kv, self_kv, 0, 0, E, sa.num_heads, sa.head_dim, key_valid=hist_valid)
         x = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x)
-        x = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if isinstance(memory_kv, RawMemory):  # K21: attend the raw memory rows with the K / V projections absorbed into q and the output
-            x = ca.cross_attention_absorbed(x, memory_kv.rows, memory_valid, residual=x)
+            x = ca.cross_attention_absorbed(x, memory_kv.rows, memory_valid, ln_in=n2)
         else:
-            x = ca.cross_attention(x, None, memory_valid, residual=x, kv=memory_kv)
-        x = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            x = ca.cross_attention(x, None, memory_valid, kv=memory_kv, ln_in=n2)
+        if fused:
+            h, x = ops.ln_linear(x, n3, self.linear1.weight, self.linear1.bias, act=self.activation)
+            return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x)
+        x = ops.layer_norm(x, *n3)
         return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
                        residual=x)
 

@@ -79,12 +79,16 @@ class MultiheadAttention(nn.Module):
         self._absorbed = (stamp, pack)
         return pack
 
-    def cross_attention_absorbed(self, x, memory, memory_valid=None, residual=None):
-        """x [N, 1, E] (one decode position per sequence), memory [N, S, E] RAW bf16 rows -> out_proj(attention) (+ residual)."""
+    def cross_attention_absorbed(self, x, memory, memory_valid=None, residual=None, ln_in=None):
+        """x [N, 1, E] (one decode position per sequence), memory [N, S, E] RAW bf16 rows -> out_proj(attention) (+ residual).
+        ``ln_in`` = (gamma, beta, eps): x is normalised first (in the prologue of the query projection) and LN(x) is the residual."""
         E, h, d = self.embed_dim, self.num_heads, self.head_dim
         N = x.shape[0]
         pk = self.absorbed()
-        qp = ops.linear(x.reshape(N, E), pk["wqk"], pk["bqk"])            # [N, heads E]
+        if ln_in is not None:
+            qp, residual = ops.ln_linear(x.reshape(N, E), ln_in, pk["wqk"], pk["bqk"])
+        else:
+            qp = ops.linear(x.reshape(N, E), pk["wqk"], pk["bqk"])        # [N, heads E]
         ctx = ops.attention_decode_mqa(qp, memory, memory_valid)          # [N, heads E]: head h's context at columns E h ..
         o = torch.empty(N, E, dtype=ctx.dtype, device=ctx.device)
         # o[:, h d .. h d + d) = ctx[:, E h .. E h + E) Wv_h^T, the eight heads as one batched launch
@@ -92,10 +96,15 @@ class MultiheadAttention(nn.Module):
         res2 = None if residual is None else residual.reshape(N, E)
         return ops.linear(o, pk["wo"], pk["bo"], residual=res2).reshape(N, 1, E)
 
-    def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None, ln=None):
-        """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention); ``ln``: see self_attention."""
+    def cross_attention(self, x, memory, memory_valid=None, residual=None, p_res=0.0, kv=None, ln=None, ln_in=None):
+        """x [N, Lq, E], memory [N, S, E] (or a precomputed ``kv``) -> out_proj(attention); ``ln``: see self_attention.  ``ln_in`` (decode
+        step, with ``kv``): x is normalised first, in the prologue of the query projection, and LN(x) is the residual."""
         E = self.embed_dim
-        if kv is None:
+        if ln_in is not None:
+            if kv is None:
+                raise RuntimeError("cross_attention(ln_in=...) is the decode-step form: pass the cached projections as kv")
+            q, residual = ops.ln_linear(x, ln_in, self.in_proj_weight[:E], self.in_proj_bias[:E])
+        elif kv is None:
             # both halves of the packed in-projection are used here: one gradient concatenation instead of two zero-filled slices + an add
             (wq, wkv), (bq, bkv) = ops.split_param_rows(self.in_proj_weight, E), ops.split_param_rows(self.in_proj_bias, E)
             q = ops.linear(x, wq, bq)

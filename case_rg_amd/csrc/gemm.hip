@@ -39,6 +39,8 @@ struct Args {
   float* rowsum;     // case_gemm_dw_bias: pre-zeroed f32 [M], receives sum_k op(A)[m, k] (the bias gradient of a weight-gradient GEMM)
   float* slabs;      // case_gemm_dw_slabs: split s of a split-K call stores its partial tile into slabs + s * slab_stride (no atomics)
   int64_t slab_stride;
+  // case_gemm_ln: LayerNorm of the A rows as a prologue of the small-problem kernel (K = 512); ln_out [M, K] receives LN(A) (nullable)
+  const float* ln_gamma; const float* ln_beta; void* ln_out; float ln_eps;
 };
 
 // The kernel body is parameterised by the workgroup size (gemm_impl.inc): 256 threads = 4 waves x (64x64) per 128x128
@@ -106,6 +108,9 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
   a.rowsum = nullptr;
   a.slabs = nullptr;
   a.slab_stride = 0;
+  a.ln_gamma = a.ln_beta = nullptr;
+  a.ln_out = nullptr;
+  a.ln_eps = 0.f;
   a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
   // 16-byte loads need the contiguous extent, every leading stride and the base to be 16-byte multiples
   auto aligned = [&](const void* p, int64_t ld, int64_t s1, int64_t s2, int64_t extent) {
@@ -226,6 +231,35 @@ extern "C" int case_gemm_dw_slabs(const CaseGemmDesc* d, const void* A, const vo
   return case_check_launch("case_gemm_dw_slabs");
 }
 
+// C = epilogue(LN(A) B^T ...): the LayerNorm that feeds a small projection (the greedy step's LN1 -> QKV, LN2 -> cross-attention query,
+// LN3 -> feed-forward; common/TransformerDecoder.py:76-89 at one position per sequence) as a PROLOGUE of the 64 x 64 small-problem kernel,
+// whose A panel (64 rows x the whole K = 512) sits in LDS anyway: every workgroup normalises its 64 rows in place (two-pass mean / variance
+// in f32, as case_layernorm_fwd) before the MFMA loop; the workgroups of the first column tile also store LN(A) to ln_out (the residual of
+// the layer's next GEMM reads it).  One launch of ~10 us per LayerNorm gone from the step (24 per greedy step at 4 + 4 layers).
+extern "C" int case_gemm_ln(const CaseGemmDesc* d, const void* A, const float* gamma, const float* beta, float eps, void* ln_out, const void* B,
+                            void* C, const float* bias_col, const void* aux, case_stream_t stream) {
+  Args a;
+  int tile = 0;
+  CASE_REQUIRE(d && gamma && beta, "case_gemm_ln: null argument");
+  CaseGemmDesc dd = *d;
+  dd.tile = 64;
+  const int rc = prepare(&dd, A, B, C, bias_col, nullptr, aux, nullptr, a, &tile);
+  if (rc) return rc;
+  if (!(tile == 64 && d->K == 512 && d->lda == 512 && !d->a_kmajor && a.split_k == 1 && d->in_dtype == CASE_BF16 && d->batch1 * d->batch2 == 1 &&
+        !(d->epilogue & (CASE_EPI_ATOMIC | CASE_EPI_BIAS_ROW | CASE_EPI_DROPOUT))))
+    return case_set_error(CASE_E_UNSUPPORTED, "case_gemm_ln: built for bf16 rows of K = lda = 512 (k-contiguous A), M and N multiples of 64, "
+                                              "unsplit, unbatched, without dropout (run case_layernorm_fwd + case_gemm)");
+  CASE_REQUIRE((uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0 && (ln_out == nullptr || (uintptr_t)ln_out % 16 == 0),
+               "case_gemm_ln: gamma / beta / ln_out must be 16-byte aligned");
+  a.ln_gamma = gamma;
+  a.ln_beta = beta;
+  a.ln_out = ln_out;
+  a.ln_eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->out_dtype == CASE_BF16) return gemm_sm::launch<bf16_t, true>(a, d->epilogue, false, d->b_kmajor, s);
+  return gemm_sm::launch<float, true>(a, d->epilogue, false, d->b_kmajor, s);
+}
+
 extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
                          const float* bias_row, const void* aux, void* aux_out, case_stream_t stream) {
   Args a;
@@ -241,8 +275,8 @@ extern "C" int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, vo
     return gemm_t8w::launch<float, 0>(a, epi, d->a_kmajor, d->b_kmajor, cus, s);
   }
   if (tile == 64) {
-    if (d->out_dtype == CASE_BF16) return gemm_sm::launch<bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
-    return gemm_sm::launch<float>(a, epi, d->a_kmajor, d->b_kmajor, s);
+    if (d->out_dtype == CASE_BF16) return gemm_sm::launch<bf16_t, false>(a, epi, d->a_kmajor, d->b_kmajor, s);
+    return gemm_sm::launch<float, false>(a, epi, d->a_kmajor, d->b_kmajor, s);
   }
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_BF16) return gemm_w4::launch<bf16_t, bf16_t>(a, epi, d->a_kmajor, d->b_kmajor, s);
   if (d->in_dtype == CASE_BF16 && d->out_dtype == CASE_F32) return gemm_w4::launch<bf16_t, float>(a, epi, d->a_kmajor, d->b_kmajor, s);

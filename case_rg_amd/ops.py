@@ -594,6 +594,60 @@ def linear(x, w, b=None, residual=None, p_drop=0.0, out_dtype=None, ln=None):
     return LinearFn.apply(x, w, b, residual, p_drop, out_dtype)
 
 
+# LayerNorm as the prologue of a small projection (case_gemm_ln): the greedy step's LN -> Linear pairs in one launch.  "on": bf16 rows of
+# width 512, a multiple of 64 rows, inference; "off" (the default): layer_norm + linear.  MEASURED FLAT (round 5, B = 256, hipGraph replay of
+# the whole greedy pass so that host time does not count): 2.232 ms per cached step without, 2.231 ms with -- the 24 LayerNorm launches it
+# removes per step (~4 us of GPU time each outside the profiler) are paid back by the prologue, which serialises DMA -> LayerNorm -> MFMA in
+# each of the N / 64 column workgroups of a row tile; eagerly it is 0.06 ms SLOWER (more host work per call).  Built, tested, not the default.
+LN_GEMM = os.environ.get("CASE_LN_GEMM", "off")
+
+
+def ln_gemm_supported(x, out_features):
+    return (LN_GEMM == "on" and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 512 and (x.numel() // 512) % 64 == 0
+            and out_features % 64 == 0 and not torch.is_grad_enabled() and bool(A.lib.case_abi_features() & A.FEAT_GEMM_LN))
+
+
+def ln_linear(x, ln, w, b=None, act=None, residual=None):
+    """(y, xn): xn = LayerNorm(x; ln = (gamma, beta, eps)), y = act(xn W^T + b) (+ residual) -- one launch where case_gemm_ln applies
+    (see ln_gemm_supported), layer_norm + linear otherwise.  ``act``: None | "gelu" | "relu".  No autograd (inference)."""
+    gamma, beta, eps = ln
+    N = w.shape[0]
+    if not ln_gemm_supported(x, N):
+        xn = layer_norm(x, gamma, beta, eps)
+        if act is not None:
+            raise RuntimeError("ln_linear: an activation needs case_gemm_ln (check ln_gemm_supported; ops.ffn is the general path)")
+        return linear(xn, w, b, residual=residual), xn
+    x2 = x.reshape(-1, 512)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    M = x2.shape[0]
+    wc = cast_param(w, torch.bfloat16)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    xn = torch.empty_like(x2)
+    d = A.GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ld_aux = M, N, 512, 512, 512, N, N
+    d.batch1 = d.batch2 = 1
+    d.in_dtype, d.out_dtype, d.split_k, d.alpha, d.tile = A.BF16, A.BF16, 1, 1.0, 64
+    epi = 0
+    if b is not None:
+        epi |= A.EPI_BIAS_COL
+    if act == "gelu":
+        epi |= A.EPI_GELU
+    elif act == "relu":
+        epi |= A.EPI_RELU
+    elif act is not None:
+        raise ValueError("ln_linear: activation %r" % (act,))
+    res2 = None
+    if residual is not None:
+        res2 = residual.reshape(M, N)
+        res2 = res2 if res2.is_contiguous() else res2.contiguous()
+        epi |= A.EPI_RESIDUAL
+    d.epilogue = epi
+    g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    A.call("case_gemm_ln", d, _ptr(x2), _ptr(g32), _ptr(b32), float(eps), _ptr(xn), _ptr(wc), _ptr(y), _ptr(None if b is None else b.detach()),
+           _ptr(res2), _stream())
+    return y.view(*x.shape[:-1], N), xn.view(x.shape)
+
+
 # ----------------------------------------------------------------------------------------------
 # Feed-forward pair:  y = dropout_o(W2 dropout_i(act(W1 x + b1)) + b2) + residual
 #   common/TransformerEncoder.py:72-75, TransformerDecoder.py:86-88, TransformerBlock.py:28-29

@@ -44,7 +44,7 @@ enum {
  * written against (case_rg_amd/_abi.py refuses any other library).  Bumped with every struct or signature change:
  *   100 round 1 | 200 round 2 (case_gemm_dw_bias, decode, optimizer) | 300 round 3 (CaseOptTensor 56 -> 64 bytes, K16 / K17)
  *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs)
- *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode, K23 case_pointer_head_decode). */
+ *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode, K23 case_pointer_head_decode, case_gemm_ln). */
 #define CASE_ABI_VERSION 500
 int case_version(void);
 /* what the build contains, as a bit mask */
@@ -61,7 +61,8 @@ enum {
   CASE_FEAT_DECODER_CHAIN = 1u << 9,   /* K20 case_decoder_chain */
   CASE_FEAT_ATTN_DECODE_MQA = 1u << 10, /* K21 case_attention_decode_mqa */
   CASE_FEAT_POINTER_DECODE = 1u << 11,  /* K22 case_pointer_attend_decode / case_additive_key_exp */
-  CASE_FEAT_POINTER_HEAD = 1u << 12     /* K23 case_pointer_head_decode */
+  CASE_FEAT_POINTER_HEAD = 1u << 12,    /* K23 case_pointer_head_decode */
+  CASE_FEAT_GEMM_LN = 1u << 13          /* case_gemm_ln: LayerNorm prologue of the small-problem GEMM */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -127,6 +128,13 @@ typedef struct {
 
 int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
               const float* bias_row, const void* aux, void* aux_out, case_stream_t stream);
+/* LayerNorm as a PROLOGUE of the small-problem GEMM (round 5): C = epilogue(LN(A) B^T), ln_out = LN(A) -- the greedy step's
+ * LN1 -> QKV, LN2 -> cross-attention query and LN3 -> feed-forward pairs (common/TransformerDecoder.py:76-89 at one position per sequence)
+ * as one launch each.  d describes the GEMM as for case_gemm (bf16, k-contiguous A with K = lda = 512, M and N multiples of 64, unsplit,
+ * unbatched; epilogue words BIAS_COL / GELU / RELU / RESIDUAL); gamma / beta f32 [512]; ln_out [M, 512] bf16 or null.  The statistics are
+ * the two-pass f32 mean / variance of case_layernorm_fwd.  CASE_E_UNSUPPORTED for anything else (run case_layernorm_fwd + case_gemm). */
+int case_gemm_ln(const CaseGemmDesc* d, const void* A, const float* gamma, const float* beta, float eps, void* ln_out, const void* B, void* C,
+                 const float* bias_col, const void* aux, case_stream_t stream);
 
 /* case_gemm owns three tilings: 128x128 (every shape / dtype / batch), 256x256 (bf16, M % 256 == N % 256 == 0,
  * K % 64 == 0, unbatched, 16-byte aligned; eight waves, operands by LDS-DMA, persistent: csrc/gemm8w.inc) and 64x64 for small

@@ -1193,3 +1193,44 @@ def test_gemm_rejects_mismatched_aux_dtype():
     w = _rand(8, 32, seed=2)
     with pytest.raises(TypeError, match="aux"):
         ops.linear(x, w, residual=_rand(16, 8, seed=3))          # f32 residual next to bf16 activations
+
+
+@pytest.mark.parametrize("M,N,act,with_res", [(256, 1536, None, False), (64, 512, "gelu", False), (320, 4096, None, False), (128, 512, "relu", False),
+                                              (256, 512, None, True)])
+def test_layernorm_prologue_gemm_matches_layernorm_then_linear(M, N, act, with_res):
+    """case_gemm_ln (the greedy step's LN -> projection pairs in one launch): LN(x) and act(LN(x) W^T + b) (+ residual) against
+    ops.layer_norm + ops.linear / ops.ffn's first half on the same bf16 rows, and against f32 torch."""
+    ops = _ops()
+    dt = torch.bfloat16
+    old_mode, ops.LN_GEMM = ops.LN_GEMM, "on"  # (measured flat on the greedy step, so not the default: ops.LN_GEMM)
+    try:
+        _ln_prologue_case(ops, M, N, act, with_res, dt)
+    finally:
+        ops.LN_GEMM = old_mode
+
+
+def _ln_prologue_case(ops, M, N, act, with_res, dt):
+    x = (_rand(M, 512, dt=dt, seed=1) * 1.7 + 0.3).to(dt)
+    w, b = _rand(N, 512, seed=2, scale=512 ** -0.5), _rand(N, seed=3, scale=0.2)
+    gamma, beta = 1.0 + _rand(512, seed=4, scale=0.1), _rand(512, seed=5, scale=0.1)
+    res = _rand(M, N, dt=dt, seed=6) if with_res else None
+    with torch.no_grad():
+        assert ops.ln_gemm_supported(x, N)
+        y, xn = ops.ln_linear(x, (gamma, beta, 1e-5), w, b, act=act, residual=res)
+        xn0 = ops.layer_norm(x, gamma, beta, 1e-5)
+    # LN rows: the same two-pass f32 statistics as the stand-alone kernel -> at most one bf16 ulp apart on a few elements
+    assert (xn.float() - xn0.float()).abs().max().item() <= 2 ** -7 * xn0.float().abs().max().item()
+    assert (xn != xn0).float().mean().item() < 0.01
+    ref = F.linear(F.layer_norm(x.float(), (512,), gamma, beta, 1e-5).to(dt).float(), w.to(dt).float(), b)
+    ref = F.gelu(ref) if act == "gelu" else torch.relu(ref) if act == "relu" else ref
+    if with_res:
+        ref = ref + res.float()
+    _close(y, ref, 2e-2, "ln_linear N=%d act=%s" % (N, act))
+    # where the fused launch does not apply (33 rows) the same call falls back to two launches with the same values
+    with torch.no_grad():
+        xs = x[:33].contiguous()
+        assert not ops.ln_gemm_supported(xs, N)
+        if act is None:
+            y2, xn2 = ops.ln_linear(xs, (gamma, beta, 1e-5), w, b, residual=None if res is None else res[:33].contiguous())
+            _close(y2, ref[:33], 2e-2, "ln_linear fallback")
+            assert torch.equal(xn2, xn0[:33])
