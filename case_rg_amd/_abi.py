@@ -34,10 +34,6 @@ class EncoderChainDesc(C.Structure):
     _fields_ = [("rows", i64), ("width", i32), ("variant", i32), ("eps_ln2", f32), ("eps_ln1_next", f32)]
 
 
-class DecoderChainDesc(C.Structure):
-    _fields_ = [("rows", i64), ("width", i32), ("qkv_parts", i32), ("kv_row_stride", i64), ("eps_a", f32), ("eps_b", f32)]
-
-
 class SoftmaxDesc(C.Structure):
     _fields_ = [("outer", i64), ("inner", i64), ("R", i64), ("C", i64), ("causal", i32), ("in_dtype", i32),
                 ("out_dtype", i32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
@@ -110,7 +106,6 @@ SIGNATURES = {
     "case_sentence_compact": [ptr, ptr, ptr, i64, i64, i64, i64, i64, ptr],
     "case_encoder_chain_pack": [ptr, ptr, ptr, ptr, ptr, ptr],
     "case_encoder_chain": [C.POINTER(EncoderChainDesc)] + [ptr] * 14,
-    "case_decoder_chain": [C.POINTER(DecoderChainDesc)] + [ptr] * 19,
     "case_set_reserved_cus": [i32],
     "case_attention_decode_mqa": [ptr, ptr, ptr, ptr, i64, i64, i64, i32, ptr, i64, ptr],
     "case_additive_key_exp": [ptr, ptr, i64, ptr],

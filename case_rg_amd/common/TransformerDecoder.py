@@ -164,44 +164,9 @@ class TransformerDecoder(nn.Module):
         E = self.layers[0].self_attn.embed_dim
         return [torch.zeros(batch, max_len, 2 * E, dtype=like.dtype, device=like.device) for _ in self.layers]
 
-    def _step_chained(self, x, t, self_kvs, hist_valid, memory_kvs, memory_valid):
-        """The same step with the row-local stages between two attention cores as ONE launch each (ops.decoder_chain,
-        csrc/decoder_chain.hip): per layer 2 attention launches + 2 chains instead of 13 launches."""
-        N, E = x.shape[0], x.shape[2]
-        layers = list(self.layers)
-        first = layers[0]
-        x2 = x.reshape(N, E)
-        x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        kv_slot = lambda skv: (skv, t * 2 * E)  # position t of the layer's [N, Tmax, 2E] cache
-        n, q, _ = ops.decoder_chain(x2, ln_b=first.norm1, in_proj=(first.self_attn.in_proj_weight, first.self_attn.in_proj_bias), qkv_parts=3,
-                                    kv_out=kv_slot(self_kvs[0]), kv_row_stride=self_kvs[0].shape[1] * 2 * E)
-        out = None
-        for i, layer in enumerate(layers):
-            sa, ca = layer.self_attn, layer.multihead_attn
-            ctx = ops.attention(q.view(N, 1, E), self_kvs[i], self_kvs[i], 0, 0, E, sa.num_heads, sa.head_dim, key_valid=hist_valid)
-            n, q, _ = ops.decoder_chain(ctx.reshape(N, E), resid=n, proj=(sa.out_proj.weight, sa.out_proj.bias), ln_a=layer.norm2,
-                                        in_proj=(ca.in_proj_weight[:E], ca.in_proj_bias[:E]), qkv_parts=1)
-            ctx = ops.attention(q.view(N, 1, E), memory_kvs[i], memory_kvs[i], 0, 0, E, ca.num_heads, ca.head_dim, key_valid=memory_valid)
-            ffn = (layer.linear1, layer.linear2)
-            if i + 1 < len(layers):
-                nxt = layers[i + 1]
-                n, q, _ = ops.decoder_chain(ctx.reshape(N, E), resid=n, proj=(ca.out_proj.weight, ca.out_proj.bias), ln_a=layer.norm3, ffn=ffn,
-                                            ln_b=nxt.norm1, in_proj=(nxt.self_attn.in_proj_weight, nxt.self_attn.in_proj_bias), qkv_parts=3,
-                                            kv_out=kv_slot(self_kvs[i + 1]), kv_row_stride=self_kvs[i + 1].shape[1] * 2 * E)
-            else:
-                _, _, out = ops.decoder_chain(ctx.reshape(N, E), resid=n, proj=(ca.out_proj.weight, ca.out_proj.bias), ln_a=layer.norm3, ffn=ffn,
-                                              want_o=True, want_n=False)
-        return out.view(N, 1, E)
-
     def step(self, x, t, self_kvs, hist_valid, memory_kvs, memory_valid):
-        first = self.layers[0]
-        if (x.shape[1] == 1 and not self.training and not isinstance(memory_kvs[0], RawMemory) and all(kv.is_contiguous() for kv in self_kvs)
-                and ops.decoder_chain_supported(x, first.self_attn.embed_dim, first.linear1.out_features, first.activation)
-                and all(l.self_attn.embed_dim == 512 and l.linear1.out_features == 512 and l.activation == "gelu" for l in self.layers)):
-            x = self._step_chained(x, t, self_kvs, hist_valid, memory_kvs, memory_valid)
-        else:
-            for layer, skv, mkv in zip(self.layers, self_kvs, memory_kvs):
-                x = layer.step(x, t, skv, hist_valid, mkv, memory_valid)
+        for layer, skv, mkv in zip(self.layers, self_kvs, memory_kvs):
+            x = layer.step(x, t, skv, hist_valid, mkv, memory_valid)
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x

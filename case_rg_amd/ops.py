@@ -175,54 +175,6 @@ def encoder_chain(variant, x_in, resid, layer, next_layer):
 
 
 # ----------------------------------------------------------------------------------------------
-# K20 fused decoder step chain (inference, one row per sequence): the row-local stages between two attention cores in one launch
-# ----------------------------------------------------------------------------------------------
-# MEASURED AND NOT THE DEFAULT: at one row per sequence a workgroup owns 16 rows and must pull every stage's whole weight matrix (512 KiB)
-# through its own CU -- ~25 GB/s with the weights coming from HBM / MALL (the 9 GB K / V stream of each step evicts them from L2) = 20 us per
-# stage, while the single launches spread each matrix over 32 workgroups: cached step 3.93 ms chained vs 3.43 ms unchained (cfg 4, B 256).
-# "on" selects the chain (tests, A/B); anything else the single launches.
-DECODER_CHAIN = os.environ.get("CASE_DECODER_CHAIN", "off")
-
-
-def decoder_chain_supported(x, width, ffn_width, activation):
-    return (DECODER_CHAIN == "on" and x.is_cuda and x.dtype == torch.bfloat16 and width == 512 and ffn_width == 512
-            and activation == "gelu" and not torch.is_grad_enabled())
-
-
-def decoder_chain(x_in, resid=None, proj=None, ln_a=None, ffn=None, ln_b=None, in_proj=None, qkv_parts=1, kv_out=None, kv_row_stride=0,
-                  want_o=False, want_n=True):
-    """One launch of csrc/decoder_chain.hip over rows x_in [M, 512] (bf16).  ``proj`` = (W [512, 512], b) applied to x_in, + ``resid``;
-    ``ln_a`` / ``ln_b`` = nn.LayerNorm modules; ``ffn`` = (linear1, linear2) modules; ``in_proj`` = (W [512 * qkv_parts, 512], b) of the
-    attention core that follows; ``kv_out`` = (tensor, element offset) receiving k | v of row r at offset + r * kv_row_stride.
-    Returns (n, q, o): the last LayerNorm's output, the query rows, the feed-forward output (None where not produced)."""
-    M = x_in.shape[0]
-    dev = x_in.device
-    bf = torch.bfloat16
-    low = lambda w: None if w is None else cast_param(w, bf)
-    f32 = lambda t: None if t is None else t.detach()
-    d = A.DecoderChainDesc()
-    d.rows, d.width, d.qkv_parts, d.kv_row_stride = M, 512, qkv_parts, kv_row_stride
-    d.eps_a = 0.0 if ln_a is None else ln_a.eps
-    d.eps_b = 0.0 if ln_b is None else ln_b.eps
-    last_ln = ln_b is not None or (ln_a is not None and ffn is None)
-    n_out = torch.empty(M, 512, dtype=bf, device=dev) if (want_n and last_ln) else None
-    q_out = torch.empty(M, 512, dtype=bf, device=dev) if in_proj is not None else None
-    o_out = torch.empty(M, 512, dtype=bf, device=dev) if (want_o and ffn is not None) else None
-    kv_ptr = None
-    if kv_out is not None:
-        kv_ptr = kv_out[0].data_ptr() + kv_out[1] * 2
-    wp, bp = (None, None) if proj is None else proj
-    wq, bq = (None, None) if in_proj is None else in_proj
-    keep = [low(wp), None if ffn is None else low(ffn[0].weight), None if ffn is None else low(ffn[1].weight), low(wq)]
-    A.call("case_decoder_chain", d, _ptr(x_in), _ptr(resid), _ptr(keep[0]), _ptr(f32(bp)),
-           _ptr(None if ln_a is None else f32(ln_a.weight)), _ptr(None if ln_a is None else f32(ln_a.bias)),
-           _ptr(keep[1]), _ptr(None if ffn is None else f32(ffn[0].bias)), _ptr(keep[2]), _ptr(None if ffn is None else f32(ffn[1].bias)),
-           _ptr(None if ln_b is None else f32(ln_b.weight)), _ptr(None if ln_b is None else f32(ln_b.bias)),
-           _ptr(keep[3]), _ptr(f32(bq)), _ptr(n_out), _ptr(q_out), kv_ptr, _ptr(o_out), _stream())
-    return n_out, q_out, o_out
-
-
-# ----------------------------------------------------------------------------------------------
 # raw GEMM launcher
 # ----------------------------------------------------------------------------------------------
 # Tiling of the GEMM calls issued from here: 0 = case_gemm's cost model, 128 / 256 = CaseGemmDesc.tile (tests and A/B

@@ -58,7 +58,7 @@ enum {
   CASE_FEAT_ATTN_RESIDENT = 1u << 6,   /* K18 / K19 behind case_attention_fwd / _bwd */
   CASE_FEAT_RESERVED_CUS = 1u << 7,    /* case_set_reserved_cus */
   CASE_FEAT_GEMM_DW_SLABS = 1u << 8,   /* case_gemm_dw_slabs: atomics-free, run-to-run deterministic split-K weight gradients */
-  CASE_FEAT_DECODER_CHAIN = 1u << 9,   /* K20 case_decoder_chain */
+  CASE_FEAT_DECODER_CHAIN = 1u << 9,   /* (reserved: K20 case_decoder_chain, retired in round 5 -- never set) */
   CASE_FEAT_ATTN_DECODE_MQA = 1u << 10, /* K21 case_attention_decode_mqa */
   CASE_FEAT_POINTER_DECODE = 1u << 11,  /* K22 case_pointer_attend_decode / case_additive_key_exp */
   CASE_FEAT_POINTER_HEAD = 1u << 12,    /* K23 case_pointer_head_decode */
@@ -507,29 +507,8 @@ int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_in, const vo
                        const float* b1, const float* b2, const float* bqkv, const float* ln2_g, const float* ln2_b,
                        const float* ln1n_g, const float* ln1n_b, void* s_out, void* qkv_out, case_stream_t stream);
 
-/* ---------------------------------------------------------------------------------------------
- * K20  the row-local stages of a decoder layer's greedy step as one launch (csrc/decoder_chain.hip; reference:
- * common/TransformerDecoder.py:76-89 on one new position per sequence, CaSE/Model.py:94-123).  bf16 rows of width 512
- * (d_model = dim_feedforward = 512, GELU).  Stages, each present when its operands are non-null, in this order:
- *   S1  y = x_in w_proj^T + b_proj (+ resid)      S2  y = LN_a(y)        S3  y = gelu(y w1^T + b1) w2^T + b2 + y   -> o_out
- *   S4  y = LN_b(y)                               n_out = the last LayerNorm's output (when no stage S3 / S4 follows S2: S2's)
- *   S5  q (| k | v) = y w_qkv^T + b_qkv           qkv_parts = 1: w_qkv [512, 512] -> q_out [rows, 512]
- *                                                 qkv_parts = 3: w_qkv [1536, 512] -> q_out, and k | v -> kv_out + row * kv_row_stride
- *                                                 (1024 contiguous elements per row: position t of a [rows, Tmax, 1024] cache)
- * Weights bf16 row-major [N, 512] (the operand copies case_gemm reads), biases / LayerNorm parameters f32.  Every intermediate is
- * rounded to bf16 where the single launches (case_gemm epilogues, case_layernorm_fwd) round it.  16-byte aligned operands.
- * ------------------------------------------------------------------------------------------- */
-typedef struct {
-  int64_t rows;           /* one row per sequence */
-  int32_t width;          /* 512 */
-  int32_t qkv_parts;      /* 1 or 3 (ignored without w_qkv) */
-  int64_t kv_row_stride;  /* elements, multiple of 4, >= 1024 */
-  float eps_a, eps_b;
-} CaseDecoderChainDesc;
-int case_decoder_chain(const CaseDecoderChainDesc* d, const void* x_in, const void* resid, const void* w_proj, const float* b_proj,
-                       const float* ln_a_g, const float* ln_a_b, const void* w1, const float* b1, const void* w2, const float* b2,
-                       const float* ln_b_g, const float* ln_b_b, const void* w_qkv, const float* b_qkv, void* n_out, void* q_out,
-                       void* kv_out, void* o_out, case_stream_t stream);
+/* (K20, case_decoder_chain -- the fused decoder step chain of round 4 -- was retired in round 5: measured slower than the single launches
+ * it replaced, 3.93 against 3.43 ms per cached step; the greedy step's time went to K21 - K23 instead.  Its feature bit stays reserved.) */
 
 /* Greedy post-processing on the device (common/Utils.py:200-217 to_sentence): per row of ids [B, T] drop the BOS / PAD ids and
  * everything from the first EOS on; out [B, T] holds the kept ids front-packed (pad behind), len [B] their count.  One host
