@@ -39,6 +39,9 @@ def family(name):
     m = re.search(r"(fa64::fwd_kernel<(?:true|false)>|fa64::bwd::bwd_kernel<(?:true|false)>|fa64::bwd::stat_kernel|splitk_reduce_kernel)", name)
     if m:
         return m.group(1)
+    m = re.search(r"(mqa_decode_kernel|pointer_attend_decode_kernel|pointer_head_decode_kernel)", name)
+    if m:
+        return m.group(1)
     m = re.search(r"(attn_decode\w*|fa_fwd\w*_kernel|fa_bwd\w*_kernel)", name)
     if m:
         return m.group(1)
