@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the encoder-forward point appended to the default line")
+    ap.add_argument("--no-decode-point", action="store_true", help="skip the greedy-decode point (cfg 4) appended to the default line")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the BASELINE workload keeps dropout on")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
     ap.add_argument("--mode", default="train", choices=["train", "decode", "encoder", "cfg5", "refdefault"],
@@ -346,7 +347,33 @@ def cpu_baseline_decode(a):
                       "x %d tokens, %d-token answer, one pass on %d threads (%.1f s)" % (a.passages, a.passage_len, a.decode_len, best, t)}
 
 
+def case_rg_amd_reset(a):
+    """Back to the training line's compute settings after an appended measurement changed them."""
+    import case_rg_amd
+    case_rg_amd.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    case_rg_amd.set_dropout(not a.no_dropout)
+
+
 def decode_main(a, device, world, rank):
+    res = decode_measure(a, device, world, rank)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_decode(a)
+    if rank == 0:
+        print(json.dumps(res))
+
+
+def decode_point(a, device):
+    """cfg 4 (BASELINE.json configs[3]: greedy decode, batch 256, 64-token answers) measured in the same process after the training
+    line, so that the driver's default run also carries the decode step's HBM roofline fraction: 2 timed passes after 1 warm-up."""
+    import copy
+    b = copy.copy(a)
+    b.batch, b.steps, b.warmup, b.graph, b.mode = 256, 2, 1, False, "decode"
+    r = decode_measure(b, device, 1, 0)
+    return {"workload": r["config"]["workload"], "answers_per_s": r["value"], "ms_per_cached_step": r["phases"]["ms_per_cached_step"],
+            "encode_plus_first_step_ms": r["phases"]["encode_plus_first_step_ms"], "roofline": r["roofline"]}
+
+
+def decode_measure(a, device, world, rank):
     """cfg 4: greedy inference, B queries x P passages, T-token answers; a "step" = one whole batch (encode + T cached steps)."""
     import case_rg_amd
     from case_rg_amd.common.CumulativeTrainer import init_params
@@ -425,10 +452,7 @@ def decode_main(a, device, world, rank):
                      "algorithmic_bytes_per_step": bytes_item_step * a.batch},
         "world_size": dist.get_world_size() if dist.is_initialized() else 1,
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_decode(a)
-    if rank == 0:
-        print(json.dumps(res))
+    return res
 
 
 def encoder_point(a, device, batch=None, steps=None, warmup=None):
@@ -625,6 +649,10 @@ def main():
         del trainer, opt, sched  # the training step's parameters, moments and cached operand copies are not needed any more
         torch.cuda.empty_cache()
         out["north_star"] = north_star_point(a, device)
+        if not a.no_decode_point and a.hidden == 512 and a.passages * a.passage_len == 3840:
+            torch.cuda.empty_cache()
+            out["decode_point"] = decode_point(a, device)
+            case_rg_amd_reset(a)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "train":
         out["cpu_baseline"] = cpu_baseline(a)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "cfg5":
