@@ -359,7 +359,7 @@ def decode_main(a, device, world, rank):
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_decode(a)
     if rank == 0:
-        print(json.dumps(res))
+        emit(res)
 
 
 def decode_point(a, device):
@@ -483,12 +483,12 @@ def encoder_point(a, device, batch=None, steps=None, warmup=None):
 def encoder_main(a, device):
     dt, flops = encoder_point(a, device)
     L, H, n = a.passage_len, a.hidden, a.batch * a.passages
-    print(json.dumps({"metric": "CaSE encoder forward (north-star point)", "value": round(n * L / dt, 1), "unit": "tokens/s", "n_gpus": 1,
+    emit({"metric": "CaSE encoder forward (north-star point)", "value": round(n * L / dt, 1), "unit": "tokens/s", "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": a.dtype,
                       "data": "synthetic", "config": {"workload": "TransformerSeqEncoder forward, %d layers, d_model %d, %d x %d x %d tokens" % (
                           a.enc_layers, H, a.batch, a.passages, L)},
                       "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_tflop": round(flops / 1e12, 3)}}))
+                                   "frac": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_tflop": round(flops / 1e12, 3)}})
 
 
 def north_star_point(a, device):
@@ -521,10 +521,30 @@ def spawn_ranks(a):
     raise SystemExit(proc.returncode)
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The ONE JSON line of the contract, on the process's original stdout.  RCCL 2.26 prints a five-line version banner to stdout when
+    its first communicator is created (seen in the one-rank rehearsal, round 5): main() therefore points file descriptor 1 at stderr for
+    the whole run and keeps the original for this call, so that whatever a library prints, stdout carries exactly one line."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
+    global _REAL_STDOUT
     a = parse()
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("CASE_BENCH_FORCE_SPAWN")):
         spawn_ranks(a)  # CASE_BENCH_FORCE_SPAWN: rehearse the self-launch with --gpus 1 on a one-GPU box
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)  # library chatter (the RCCL banner) goes to stderr
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and not (world == 1 and a.gpus <= 1):
@@ -658,7 +678,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "cfg5":
         out["cpu_baseline"] = cpu_baseline(a, max_passages=8)  # 8 of the 40 passages: ~20 s of CPU work per step
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -812,6 +812,11 @@ ATTENTION_MODE = "auto"
 SCORES_FUSED = os.environ.get("CASE_SCORES_FUSED", "1") != "0"  # the GEMM + softmax + GEMM path keeps its scores in the score GEMM's accumulators where K17 covers the shape
 _FUSED_TRAINING = (64, 96)
 _FUSED_INFERENCE = (64, 96, 320)
+# head_dim 320 in INFERENCE where K17 covers the shape (Lk <= 384): "scores" (default) = K17's score kernel + product, what training runs;
+# "slab" = the fused flash-style forward (fas_fwd_kernel).  A/B at B 256 (the greedy pass's encode phase, two runs each on one box,
+# round 5): 194.0 / 195.0 ms with the slab kernel, 190.2 / 191.0 ms with K17 -- the slab forward runs 3.87 TFLOP per 5H block in 9.2 ms
+# (422 TFLOP/s), K17's two launches move the probabilities once each way at 4-5 TB/s and take ~6.2 ms.
+INFER_320 = os.environ.get("CASE_INFER_320", "scores")
 
 
 def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, needs_grad=True):
@@ -819,6 +824,8 @@ def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, needs_grad=True):
         return False
     if ATTENTION_MODE == "auto":
         if d not in (_FUSED_TRAINING if needs_grad else _FUSED_INFERENCE):
+            return False
+        if not needs_grad and d == 320 and INFER_320 == "scores" and SCORES_FUSED and k_src.shape[1] <= 384 and k_src.shape[1] % 8 == 0:
             return False
     for t, off in ((q_src, q_off), (k_src, k_off), (v_src, v_off)):
         if t.shape[2] % 8 or off % 8 or t.data_ptr() % 16:
