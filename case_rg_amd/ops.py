@@ -812,11 +812,12 @@ ATTENTION_MODE = "auto"
 SCORES_FUSED = os.environ.get("CASE_SCORES_FUSED", "1") != "0"  # the GEMM + softmax + GEMM path keeps its scores in the score GEMM's accumulators where K17 covers the shape
 _FUSED_TRAINING = (64, 96)
 _FUSED_INFERENCE = (64, 96, 320)
-# head_dim 320 in INFERENCE where K17 covers the shape (Lk <= 384): "scores" (default) = K17's score kernel + product, what training runs;
-# "slab" = the fused flash-style forward (fas_fwd_kernel).  A/B at B 256 (the greedy pass's encode phase, two runs each on one box,
-# round 5): 194.0 / 195.0 ms with the slab kernel, 190.2 / 191.0 ms with K17 -- the slab forward runs 3.87 TFLOP per 5H block in 9.2 ms
-# (422 TFLOP/s), K17's two launches move the probabilities once each way at 4-5 TB/s and take ~6.2 ms.
-INFER_320 = os.environ.get("CASE_INFER_320", "scores")
+# head_dim 320 in INFERENCE where K17 covers the shape (Lk <= 384): "slab" (default) = the fused flash-style forward (fas_fwd_kernel, f32
+# probabilities inside the kernel); "scores" = K17's score kernel + product, what training runs.  A/B at B 256 (the greedy pass's encode
+# phase, two runs each on one box, round 5): 194.0 / 195.0 ms with the slab kernel, 190.2 / 191.0 ms with K17 (+1 % answers/s) -- NOT
+# taken: K17 rounds the probabilities to bf16 before the product and the passage-selection logits of prod_case_test [bf16_auto] then sit
+# 3.08e-2 from the reference against 2.2e-2 with the slab kernel (bar 3e-2): one per cent of throughput does not buy a wider parity bar.
+INFER_320 = os.environ.get("CASE_INFER_320", "slab")
 
 
 def _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, needs_grad=True):
