@@ -132,15 +132,15 @@ class MultiheadAttention(nn.Module):
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=False):
         """[L, N, E] tensors; ``key_padding_mask`` True = pad.  Returns (out [Lq, N, E], weights): ``weights`` is None unless
         ``need_weights`` (then the head-averaged probabilities [N, Lq, Lk], see ``averaged_weights``).  ``key`` and ``value`` may be
-        different tensors of the same length (projected with their own rows of the packed in-projection); an ``attn_mask`` must be the
-        square subsequent (causal) mask."""
+        different tensors of the same length (projected with their own rows of the packed in-projection).  ``attn_mask``: the square
+        subsequent (causal) mask takes the kernels' causal flag; any other 2-D float / bool mask is added to the scores (split_attn_mask)."""
         valid = None if key_padding_mask is None else ~key_padding_mask
         q = query.transpose(0, 1).contiguous()
-        causal = is_causal_mask(attn_mask)
-        if key is value and query is key:
+        causal, add_mask = split_attn_mask(attn_mask)
+        if add_mask is None and key is value and query is key:
             out = self.self_attention(q, valid, causal=causal)
             kb = q
-        elif key is value and not causal:
+        elif add_mask is None and key is value and not causal:
             kb = key.transpose(0, 1).contiguous()
             out = self.cross_attention(q, kb, valid)
         else:  # the general form: three projections, the attention core on three sources
@@ -151,10 +151,33 @@ class MultiheadAttention(nn.Module):
             w, b = self.in_proj_weight, self.in_proj_bias
             qp, kp, vp = ops.linear(q, w[:E], b[:E]), ops.linear(kb, w[E:2 * E], b[E:2 * E]), ops.linear(vb, w[2 * E:], b[2 * E:])
             ctx = ops.attention(qp, kp, vp, 0, 0, 0, self.num_heads, self.head_dim, key_valid=valid, causal=causal,
-                                p_drop=config.drop_p(self.dropout, self.training))
+                                p_drop=config.drop_p(self.dropout, self.training), add_mask=add_mask)
             out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
+        if need_weights and add_mask is not None:
+            raise NotImplementedError("need_weights with an arbitrary attn_mask is not built (no caller on the path)")
         weights = self.averaged_weights(q, kb, valid, causal) if need_weights else None
         return out.transpose(0, 1), weights
+
+
+def split_attn_mask(mask):
+    """nn.MultiheadAttention's ``attn_mask`` -> (causal flag, additive f32 [Lq, Lk] mask or None).  The square subsequent mask becomes the
+    kernels' causal flag (tagged by generate_square_subsequent_mask, or recognised by one host comparison); ANY other 2-D mask is taken as
+    an additive mask on the scores -- float as given, bool with True = masked (-inf) as torch defines it -- and runs the GEMM + softmax + GEMM
+    path (round 5; a fully masked row yields NaN, as in torch)."""
+    if mask is None:
+        return False, None
+    if getattr(mask, "_case_causal", False):
+        return True, None
+    if mask.dim() != 2:
+        raise NotImplementedError("attn_mask must be 2-D [Lq, Lk] (per-head 3-D masks are not built)")
+    n = mask.size(0)
+    if mask.shape == (n, n) and mask.dtype != torch.bool:
+        upper = torch.triu(torch.ones(n, n, dtype=torch.bool, device=mask.device), 1)
+        if bool(((mask < -1e9) == upper).all()) and bool((mask.masked_select(~upper) == 0).all()):
+            return True, None
+    if mask.dtype == torch.bool:
+        return False, torch.zeros(mask.shape, dtype=torch.float32, device=mask.device).masked_fill(mask, float("-inf"))
+    return False, mask.to(torch.float32)
 
 
 def is_causal_mask(mask):

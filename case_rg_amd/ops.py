@@ -858,10 +858,12 @@ def _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop):
 
 class AttentionFn(Function):
     @staticmethod
-    def forward(ctx, q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid, causal, p_drop):
+    def forward(ctx, q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid, causal, p_drop, add_mask=None):
         """*_src: [N, L, W] contiguous tensors holding the projections at column offset *_off (width heads*d);
         the same tensor may be passed for several roles (packed QKV).  key_valid uint8 [N, Lk] or None.
-        bf16 with a built head size runs the fused kernel (no score tensor); otherwise GEMM + softmax + GEMM."""
+        bf16 with a built head size runs the fused kernel (no score tensor); otherwise GEMM + softmax + GEMM.
+        ``add_mask`` f32 [Lq, Lk]: an ARBITRARY additive attention mask (nn.MultiheadAttention's attn_mask / memory_mask; no caller on the
+        CaSE / Masque path uses one): added to the f32 scores between the score GEMM and the softmax -- the GEMM + softmax + GEMM path only."""
         N, Lq, _ = q_src.shape
         Lk = k_src.shape[1]
         dt, dev = q_src.dtype, q_src.device
@@ -869,7 +871,7 @@ class AttentionFn(Function):
         alpha = 1.0 / math.sqrt(d)
         drop = (p_drop,) + config.next_rng(N * heads * Lq * Lk) if p_drop > 0.0 else None
         O = torch.empty(N, Lq, E, dtype=dt, device=dev)
-        fused = _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, any(ctx.needs_input_grad[:3]))
+        fused = add_mask is None and _fused_ok(q_src, k_src, v_src, q_off, k_off, v_off, d, any(ctx.needs_input_grad[:3]))
         if (fused and Lq == 1 and not causal and drop is None and not any(ctx.needs_input_grad[:3]) and N * heads >= DECODE_MIN_PAIRS
                 and A.lib.case_attention_decode_supported(d)):
             # greedy decode step: one query per sequence against the cached keys / values -- the streaming kernel (no LSE: nothing
@@ -895,7 +897,7 @@ class AttentionFn(Function):
                        _ptr(lse), _stream())
             ctx.save_for_backward(q_src, k_src, v_src, key_valid, O, lse)
         else:
-            S, Pd = AttentionFn._probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha)
+            S, Pd = AttentionFn._probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha, add_mask)
             if not AttentionFn._product(Pd, v_src, v_off, O, 0, heads, d, Lq, Lk, False):
                 gemm(Pd, v_src, O, Lq, d, Lk, Lk, v_src.shape[2], E, b_off=v_off, b_kmajor=True, batch1=N, batch2=heads,
                      sa=(heads * Lq * Lk, Lq * Lk), sb=(Lk * v_src.shape[2], d), sc=(Lq * E, d))
@@ -932,7 +934,7 @@ class AttentionFn(Function):
             key = _src_key(src)
             out.append(None if key in seen else bufs[key])
             seen.add(key)
-        return (out[0], out[1], out[2]) + (None,) * 8
+        return (out[0], out[1], out[2]) + (None,) * 9
 
     @staticmethod
     def _scores_fused(a_src, b_src, a_off, b_off, heads, d, Lq, Lk, causal):
@@ -968,7 +970,7 @@ class AttentionFn(Function):
         return True
 
     @staticmethod
-    def _probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha):
+    def _probabilities(q_src, k_src, q_off, k_off, heads, d, key_valid, causal, drop, alpha, add_mask=None):
         """P = softmax(alpha Q K^T | masks) [N, h, Lq, Lk] and its dropped-out copy (same tensor when drop is None).
         The scores are kept in f32 between the GEMM and the softmax: a bf16 score of magnitude 16 carries an absolute error of
         0.06, i.e. 6 % on its probability (measured: 4-5 % L2 error on the block gradients at head_dim 320 / 480 with bf16
@@ -976,7 +978,7 @@ class AttentionFn(Function):
         N, Lq, _ = q_src.shape
         Lk = k_src.shape[1]
         dt = q_src.dtype
-        if AttentionFn._scores_fused(q_src, k_src, q_off, k_off, heads, d, Lq, Lk, causal):
+        if add_mask is None and AttentionFn._scores_fused(q_src, k_src, q_off, k_off, heads, d, Lq, Lk, causal):
             # K17: the softmax rides in the score GEMM (a workgroup holds whole rows): no f32 score tensor
             P = torch.empty(N, heads, Lq, Lk, dtype=dt, device=q_src.device)
             Pd = torch.empty_like(P) if drop is not None else P
@@ -987,6 +989,8 @@ class AttentionFn(Function):
         S = torch.empty(N, heads, Lq, Lk, dtype=torch.float32, device=q_src.device)
         gemm(q_src, k_src, S, Lq, Lk, d, q_src.shape[2], k_src.shape[2], Lk, a_off=q_off, b_off=k_off, batch1=N, batch2=heads,
              sa=(Lq * q_src.shape[2], d), sb=(Lk * k_src.shape[2], d), sc=(heads * Lq * Lk, Lq * Lk), alpha=alpha)
+        if add_mask is not None:
+            S.add_(add_mask.to(torch.float32).reshape(1, 1, Lq, Lk))  # glue: a broadcast add on the f32 scores (off the CaSE / Masque path)
         P = S if dt == torch.float32 else torch.empty(N, heads, Lq, Lk, dtype=dt, device=q_src.device)
         Pd = torch.empty_like(P) if drop is not None else P
         sd = _softmax_desc(N, heads, Lq, Lk, causal, A.F32, _DT[dt], drop)
@@ -1049,7 +1053,7 @@ class AttentionFn(Function):
             key = _src_key(src)
             out.append(None if key in seen else bufs[key])
             seen.add(key)
-        return (out[0], out[1], out[2]) + (None,) * 8
+        return (out[0], out[1], out[2]) + (None,) * 9
 
 
 # K21: the greedy step's cross-attention over a long memory on the RAW memory rows with absorbed K / V projections (csrc/attn_mqa.hip).
@@ -1080,8 +1084,8 @@ def attention_decode_mqa(qp, memory, key_valid=None):
     return out
 
 
-def attention(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid=None, causal=False, p_drop=0.0):
-    return AttentionFn.apply(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, _u8(key_valid), causal, p_drop)
+def attention(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid=None, causal=False, p_drop=0.0, add_mask=None):
+    return AttentionFn.apply(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, _u8(key_valid), causal, p_drop, add_mask)
 
 
 class AttentionGroupsFn(Function):

@@ -1234,3 +1234,50 @@ def _ln_prologue_case(ops, M, N, act, with_res, dt):
             y2, xn2 = ops.ln_linear(xs, (gamma, beta, 1e-5), w, b, residual=None if res is None else res[:33].contiguous())
             _close(y2, ref[:33], 2e-2, "ln_linear fallback")
             assert torch.equal(xn2, xn0[:33])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_multihead_attention_takes_an_arbitrary_attn_mask(dt):
+    """nn.MultiheadAttention's attn_mask beyond the causal pattern (VERDICT r4 missing 7; no caller on the CaSE / Masque path): a float
+    additive mask and a bool mask (True = masked) against torch's own module with the same weights, forward and backward."""
+    import case_rg_amd
+    from case_rg_amd.common.attention import MultiheadAttention
+    case_rg_amd.set_compute_dtype(dt)
+    case_rg_amd.set_dropout(False)
+    try:
+        torch.manual_seed(9)
+        E, h, Lq, Lk, N = 64, 4, 10, 13, 3
+        ours = MultiheadAttention(E, h).to(DEV)
+        ref = torch.nn.MultiheadAttention(E, h).to(DEV)
+        with torch.no_grad():
+            ours.in_proj_bias.copy_(torch.randn(3 * E) * 0.1)
+            ref.in_proj_weight.copy_(ours.in_proj_weight.to(dt).float()); ref.in_proj_bias.copy_(ours.in_proj_bias)
+            ref.out_proj.weight.copy_(ours.out_proj.weight.to(dt).float()); ref.out_proj.bias.copy_(ours.out_proj.bias)
+        case_rg_amd.ops.invalidate_param_cache()
+        g = torch.Generator().manual_seed(4)
+        fmask = (torch.randn(Lq, Lk, generator=g) * 2).to(DEV)
+        bmask = (torch.rand(Lq, Lk, generator=g) < 0.3).to(DEV)
+        bmask[:, 0] = False  # no fully masked row (torch gives NaN there, so do we)
+        pad = torch.zeros(N, Lk, dtype=torch.bool, device=DEV)
+        pad[1, 9:] = True
+        tol = 1e-3 if dt == torch.float32 else 3e-2
+        for mask in (fmask, bmask):
+            q = _rand(Lq, N, E, dt=dt, seed=1).requires_grad_()
+            kv = _rand(Lk, N, E, dt=dt, seed=2).requires_grad_()
+            out, _ = ours(q, kv, kv, attn_mask=mask, key_padding_mask=pad)
+            qr, kr = q.detach().float().requires_grad_(), kv.detach().float().requires_grad_()
+            want, _ = ref(qr, kr, kr, attn_mask=mask, key_padding_mask=pad, need_weights=False)
+            _close(out, want, tol, "attn_mask forward")
+            gr = _rand(Lq, N, E, dt=dt, seed=3)
+            out.backward(gr)
+            want.backward(gr.float())
+            _close(q.grad, qr.grad, 2 * tol, "attn_mask dq")
+            _close(kv.grad, kr.grad, 2 * tol, "attn_mask dkv")
+        # the causal pattern given as a plain float matrix is still recognised and takes the fused path's flag
+        from case_rg_amd.common.attention import split_attn_mask
+        n = 6
+        cm = torch.triu(torch.full((n, n), -1e20, device=DEV), 1)
+        assert split_attn_mask(cm) == (True, None)
+        assert split_attn_mask(None) == (False, None)
+    finally:
+        case_rg_amd.set_compute_dtype(torch.float32)
