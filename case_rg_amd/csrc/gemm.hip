@@ -150,6 +150,15 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
 }
 }  // namespace
 
+#ifdef G8_CLOCK_STAMPS  // measurement builds only: (shader cycles, 100 MHz ticks) workgroup 0 of the LAST 8-wave launch spent between its first and last instruction
+extern "C" int case_debug_gemm_clock(unsigned long long* out2) {
+  unsigned long long h[4];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gemm_t8w::g_clock_stamps), sizeof(h)) != hipSuccess) return 1;
+  out2[0] = h[2] - h[0];
+  out2[1] = h[3] - h[1];
+  return 0;
+}
+#endif
 extern "C" int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const void* B, const void* C, const float* bias_col,
                                   const void* aux, const void* aux_out) {
   Args a;

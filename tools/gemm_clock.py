@@ -36,20 +36,32 @@ class Sampler(threading.Thread):
     def run(self):
         while not self.stop:
             if self.on:
+                clk, pw = None, None
                 for p in self.sclk[:1]:
                     for line in read(p).splitlines():
                         if line.rstrip().endswith("*"):
-                            self.clk.append(float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", "")))
+                            clk = float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
                 for p in self.power[:1]:
                     v = read(p).strip()
                     if v:
-                        self.pw.append(float(v) / 1e6)
+                        pw = float(v) / 1e6
+                if clk is not None and pw is not None:
+                    self.clk.append(clk)
+                    self.pw.append(pw)
             time.sleep(0.02)
 
     def window(self):
+        """(mean clock, min clock, mean power) over the samples taken under load: those whose power is within 15 % of the window's maximum
+        (the sysfs reads go through the SMU and some of them return only after the queue has drained)."""
         c, p = self.clk, self.pw
         self.clk, self.pw = [], []
-        return (round(sum(c) / len(c)) if c else None, round(min(c)) if c else None, round(sum(p) / len(p)) if p else None)
+        n = min(len(c), len(p))
+        if n == 0:
+            return None, None, None
+        top = max(p[:n])
+        busy = [i for i in range(n) if p[i] >= 0.85 * top]
+        cb, pb = [c[i] for i in busy], [p[i] for i in busy]
+        return round(sum(cb) / len(cb)), round(min(cb)), round(sum(pb) / len(pb))
 
 
 def main():
@@ -81,7 +93,7 @@ def main():
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
-            iters = 400  # ~4 s: the sysfs reads go through the SMU and take tens of milliseconds each
+            iters = 800  # ~4 s: the sysfs reads go through the SMU and take tens of milliseconds each
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(iters):
@@ -98,8 +110,17 @@ def main():
             smp.on = False
             torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / iters * 1e-3
+            stamp = None
+            if hasattr(A.lib, "case_debug_gemm_clock") and not name.startswith("vendor"):  # G8_CLOCK_STAMPS build: exact, from inside the last launch
+                import ctypes
+                two = (ctypes.c_ulonglong * 2)()
+                A.lib.case_debug_gemm_clock.restype = ctypes.c_int
+                if A.lib.case_debug_gemm_clock(two) == 0 and two[1]:
+                    stamp = round(two[0] / two[1] * 100.0)
             clk, clk_min, pw = smp.window()
             rec = {"data": data, "form": name, "ms": round(t * 1e3, 3), "tflops": round(2.0 * M * N * K / t / 1e12, 1), "sclk_mhz_avg": clk, "sclk_mhz_min": clk_min, "power_w_avg": pw}
+            if stamp:
+                rec["sclk_mhz_in_kernel"] = clk = stamp  # s_memtime / s_memrealtime (100 MHz) inside workgroup 0 of the last launch
             if clk:
                 rec["peak_at_that_clock_tflops"] = round(256 * 4 * 1024 * clk * 1e6 / 1e12, 1)
                 rec["frac_of_peak_at_that_clock"] = round(rec["tflops"] / rec["peak_at_that_clock_tflops"], 3)
