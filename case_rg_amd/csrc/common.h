@@ -43,6 +43,7 @@ template <> struct Elem<bf16_t> {
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
   static constexpr int N = 4;
+  typedef uint4 raw;
   static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[4]) {
     v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
   }
@@ -56,6 +57,7 @@ template <> struct Vec16<float> {
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
+  typedef uint4 raw;
   static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -70,6 +72,22 @@ template <> struct Vec16<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// 8-byte vector access for bf16 rows whose width is a multiple of 256 but not of 512 elements (64 lanes x 4): widths 256, 768, 1280 of the
+// reference's default geometry and of cfg 5
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  static constexpr int N = 4;
+  typedef uint2 raw;
+  static __device__ __forceinline__ void unpack(const uint2& t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) { unpack(*reinterpret_cast<const uint2*>(p), v); }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
   }
 };
 

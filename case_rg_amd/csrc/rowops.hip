@@ -280,15 +280,17 @@ struct LnDrop {
   float p;
   uint64_t seed, offset;
 };
-template <typename T>
-__device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, const float (&o)[Vec16<T>::N]) {
-  constexpr int E = Vec16<T>::N;
+template <typename T, typename V = Vec16<T>>
+__device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, const float (&o)[V::N]) {
+  constexpr int E = V::N;
   float q[E];
   if constexpr (sizeof(T) == 2) {
-    uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(o[2 * i], o[2 * i + 1]);
-    Vec16<T>::unpack(make_uint4(w[0], w[1], w[2], w[3]), q);
+    for (int i = 0; i < E; i += 2) {  // the value the separate pass would have read back: dx rounded to bf16
+      const uint32_t w = f32x2_to_bf16x2(o[i], o[i + 1]);
+      q[i] = __uint_as_float(w << 16);
+      q[i + 1] = __uint_as_float(w & 0xffff0000u);
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < E; ++e) q[e] = o[e];
@@ -301,7 +303,7 @@ __device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, 
     q[e] = u0 >= dr.p ? q[e] * scale : 0.f;
     q[e + 1] = u1 >= dr.p ? q[e + 1] * scale : 0.f;
   }
-  Vec16<T>::store(reinterpret_cast<T*>(dr.out) + idx, q);
+  V::store(reinterpret_cast<T*>(dr.out) + idx, q);
 }
 
 // Backward.  One wave per row, the row in registers; the raw 16-byte vectors of the wave's NEXT row (x, dy and the optional
@@ -309,14 +311,15 @@ __device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, 
 // the row is a dependent chain (load -> two wave reductions -> store) and with one row in flight per wave the kernel ran at
 // 1.4-1.7 TB/s on streams that do not fit the Infinity Cache (copy ceiling 6.3 TB/s).  The loop body is branch-free (cols ==
 // NV * 64 * E, optional streams are template flags): behind a conditional load hipcc waits vmcnt(0) and drains the prefetch.
-template <typename T, int NV, bool HAS_X2, bool HAS_ADD, bool DROP2 = false>
+template <typename T, int NV, bool HAS_X2, bool HAS_ADD, bool DROP2 = false, typename V = Vec16<T>>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ x2, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          T* __restrict__ dx, const T* __restrict__ dx_add,
                                                          float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
                                                          int64_t cols, const LnDrop dr = LnDrop()) {
-  constexpr int E = Vec16<T>::N;
+  constexpr int E = V::N;
+  typedef typename V::raw raw_t;
   extern __shared__ float part[];  // [4 waves][2][cols] column partials, summed and added to d_gamma / d_beta at the end
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + wid, nwaves = (int64_t)gridDim.x * 4;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
     }
   }
   struct Raw {  // a row stays packed (16 bytes per stream and chunk) between the two passes
-    uint4 x[NV], d[NV], x2[HAS_X2 ? NV : 1], add[HAS_ADD ? NV : 1];
+    raw_t x[NV], d[NV], x2[HAS_X2 ? NV : 1], add[HAS_ADD ? NV : 1];
     float mu, rs;
   };
   auto request = [&](Raw& w, int64_t r) {
@@ -341,17 +344,17 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int64_t o = base + (int64_t)i * 64 * E;
-      w.x[i] = *reinterpret_cast<const uint4*>(x + o);
-      w.d[i] = *reinterpret_cast<const uint4*>(dy + o);
-      if constexpr (HAS_X2) w.x2[i] = *reinterpret_cast<const uint4*>(x2 + o);
-      if constexpr (HAS_ADD) w.add[i] = *reinterpret_cast<const uint4*>(dx_add + o);
+      w.x[i] = *reinterpret_cast<const raw_t*>(x + o);
+      w.d[i] = *reinterpret_cast<const raw_t*>(dy + o);
+      if constexpr (HAS_X2) w.x2[i] = *reinterpret_cast<const raw_t*>(x2 + o);
+      if constexpr (HAS_ADD) w.add[i] = *reinterpret_cast<const raw_t*>(dx_add + o);
     }
   };
   auto normalised = [&](const Raw& w, int i, float (&xh)[E]) {
-    Vec16<T>::unpack(w.x[i], xh);
+    V::unpack(w.x[i], xh);
     if constexpr (HAS_X2) {
       float t[E];
-      Vec16<T>::unpack(w.x2[i], t);
+      V::unpack(w.x2[i], t);
 #pragma unroll
       for (int e = 0; e < E; ++e) xh[e] += t[e];
     }
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
     for (int i = 0; i < NV; ++i) {
       float xh[E], d[E];
       normalised(cur, i, xh);
-      Vec16<T>::unpack(cur.d[i], d);
+      V::unpack(cur.d[i], d);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const float gy = d[e] * g[i][e];
@@ -382,17 +385,17 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
     for (int i = 0; i < NV; ++i) {
       float xh[E], d[E], o[E];
       normalised(cur, i, xh);
-      Vec16<T>::unpack(cur.d[i], d);
+      V::unpack(cur.d[i], d);
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] = cur.rs * (d[e] * g[i][e] - m1 - xh[e] * m2);
       if constexpr (HAS_ADD) {  // a second gradient of the same tensor (its residual use), summed here instead of by a separate pass
         float w[E];
-        Vec16<T>::unpack(cur.add[i], w);
+        V::unpack(cur.add[i], w);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] += w[e];
       }
-      Vec16<T>::store(dx + r * cols + ((int64_t)i * 64 + lane) * E, o);
-      if constexpr (DROP2) ln_store_dropped<T>(dr, r * cols + ((int64_t)i * 64 + lane) * E, o);
+      V::store(dx + r * cols + ((int64_t)i * 64 + lane) * E, o);
+      if constexpr (DROP2) ln_store_dropped<T, V>(dr, r * cols + ((int64_t)i * 64 + lane) * E, o);
     }
     cur = nxt;
   }
@@ -560,6 +563,22 @@ void ln_bwd_vec_launch(const void* dy, const void* x, const void* x2, const floa
                        hipStream_t s) {
   constexpr int E = Vec16<T>::N;
   const int nv = (int)((cols + 64 * E - 1) / (64 * E));
+  if constexpr (sizeof(T) == 2) {
+    // bf16 rows of 256, 768 or 1280 elements (odd multiples of 256: hidden 256 of the reference's defaults and its 5H rows, 768 of cfg 5): the
+    // same pipelined one-wave-per-row kernel on 8-byte vectors (64 lanes x 4 elements per chunk) instead of the guarded form below
+    if (cols % 256 == 0 && cols % 512 != 0 && cols <= 1280) {
+      const int grid = grid_for(rows, 4, 8, 256 * 8);
+      const size_t lds = 8 * cols * sizeof(float);
+#define LN8(NVV, X2, ADD) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV, X2, ADD, false, Vec8<T>>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
+#define LN8B(NVV) do { if (x2 && dx_add) LN8(NVV, true, true); else if (x2) LN8(NVV, true, false); else if (dx_add) LN8(NVV, false, true); else LN8(NVV, false, false); } while (0)
+      if (cols == 256) LN8B(1);
+      else if (cols == 768) LN8B(3);
+      else LN8B(5);
+#undef LN8B
+#undef LN8
+      return;
+    }
+  }
   if (cols != (int64_t)nv * 64 * E || nv > 8) {  // ragged last chunk: guarded kernel
     const int grid = grid_for(rows, 4, 16, 256 * 4);
     const size_t lds = 2 * cols * sizeof(float);
@@ -926,8 +945,20 @@ bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const
                         float* db, int64_t rows, int64_t cols, const LnDrop& dr, hipStream_t s) {
   constexpr int E = Vec16<T>::N;
   const int nv = (int)((cols + 64 * E - 1) / (64 * E));
-  if (cols != (int64_t)nv * 64 * E || nv > 8) return false;
   const T* nul = nullptr;
+  if constexpr (sizeof(T) == 2) {
+    if (cols % 256 == 0 && cols % 512 != 0 && cols <= 1280) {  // 8-byte-vector form, see ln_bwd_vec_launch
+      const int grid = grid_for(rows, 4, 8, 256 * 8);
+      const size_t lds = 8 * cols * sizeof(float);
+#define LN8D(NVV) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NVV, false, false, true, Vec8<T>>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, nul, gamma, mean, rstd, (T*)dx, nul, dg, db, rows, cols, dr)
+      if (cols == 256) LN8D(1);
+      else if (cols == 768) LN8D(3);
+      else LN8D(5);
+#undef LN8D
+      return true;
+    }
+  }
+  if (cols != (int64_t)nv * 64 * E || nv > 8) return false;
   if constexpr (sizeof(T) == 2) {
     if (nv == 5) {  // the 5H rows of the CaSE / Masque blocks: one wave per row (see ln_bwd_drop_rows5_kernel)
       hipLaunchKernelGGL(ln_bwd_drop_rows5_kernel, dim3(grid_for(rows, 4, 8, 256 * 8)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,

@@ -260,8 +260,12 @@ def _split_for(out_rows, out_cols, k_len, elem_bytes):
     round wasted.  Splits keep >= 8 K tiles each, or >= 2 when the output has so few tiles that the chip would otherwise sit
     idle (the decoder's 512 x 512 weight gradients: 16 tiles)."""
     k_tiles = max(1, (k_len * elem_bytes + 127) // 128)
-    if elem_bytes == 2 and out_rows % 256 == 0 and out_cols % 256 == 0 and k_len % 64 == 0 and k_tiles >= 64:
-        tiles = (out_rows // 256) * (out_cols // 256)
+    tiles256 = (out_rows // 256) * (out_cols // 256)
+    # (one to three 256-tiles cannot fill the chip even at 64 splits -- the reference's default width 256: a 256 x 256 gradient over 16 000
+    #  tokens ran as ONE workgroup, 209 us -- so those go to the small tilings below)
+    if (elem_bytes == 2 and out_rows % 256 == 0 and out_cols % 256 == 0 and k_len % 64 == 0 and k_tiles >= 64
+            and tiles256 * min(64, k_tiles // 8) >= 230):
+        tiles = tiles256
         best, best_score = 1, -1.0
         for split in range(1, 65):
             if split > 1 and k_tiles // split < 8:
