@@ -761,8 +761,10 @@ void set_lds(KernelT kernel, size_t bytes) {
 
 // Geometry per head size: NS head-dim slices, NQ stationary blocks per workgroup, TS streamed rows per tile
 template <int D> struct Plan;
+template <> struct Plan<32> { static constexpr int NS = 1, NQ = 4, TS = 64, MINW = 2; };   // the reference's default width 256: 8 heads of 32
 template <> struct Plan<64> { static constexpr int NS = 1, NQ = 4, TS = 64, MINW = 2; };
 template <> struct Plan<96> { static constexpr int NS = 1, NQ = 4, TS = 64, MINW = 2; };
+template <> struct Plan<160> { static constexpr int NS = 1, NQ = 4, TS = 32, MINW = 2; };  // its 5H blocks (1280 / 8): one slice as wide as 320's two
 template <> struct Plan<320> { static constexpr int NS = 2, NQ = 4, TS = 32, MINW = 2; };
 template <> struct Plan<480> { static constexpr int NS = 3, NQ = 2, TS = 32, MINW = 2; };
 
@@ -821,7 +823,7 @@ int launch_bwd(FaArgs a, const BwdOut& g, const bf16_t* out, float* delta, hipSt
   static bool attr = false;
   a.tiles = (a.Lq + 32 * NQ - 1) / (32 * NQ);
   a.nblk = a.tiles * a.heads * a.N;
-  if constexpr (NS == 1) {
+  if constexpr (NS == 1 && D <= 96) {  // (a 160-wide slice takes dK and dV in two launches like the split head dims: both at once do not fit the registers)
     const size_t lds_dkv = (size_t)TS * (2 * RS + 2 * TR) + 3 * TS * 4;
     auto kdkv = &fa_bwd_dkv_kernel<D, NS, NQ, TS, P::MINW, 3>;
     if (!attr) {
@@ -879,9 +881,12 @@ int fill_args(FaArgs& a, const CaseAttnDesc* d, const void* q, const void* k, co
 
 template <int D> int queries_per_wg() { return 32 * Plan<D>::NQ; }
 int queries_per_wg_of(int64_t d) {
-  return d == 64 ? queries_per_wg<64>() : d == 96 ? queries_per_wg<96>() : d == 320 ? queries_per_wg<320>() : queries_per_wg<480>();
+  return d == 32 ? queries_per_wg<32>() : d == 64 ? queries_per_wg<64>() : d == 96 ? queries_per_wg<96>() : d == 160 ? queries_per_wg<160>()
+       : d == 320 ? queries_per_wg<320>() : queries_per_wg<480>();
 }
-int tile_rows_of(int64_t d) { return d == 64 ? Plan<64>::TS : d == 96 ? Plan<96>::TS : d == 320 ? Plan<320>::TS : Plan<480>::TS; }
+int tile_rows_of(int64_t d) {
+  return d == 32 ? Plan<32>::TS : d == 64 ? Plan<64>::TS : d == 96 ? Plan<96>::TS : d == 160 ? Plan<160>::TS : d == 320 ? Plan<320>::TS : Plan<480>::TS;
+}
 
 }  // namespace
 
@@ -890,12 +895,14 @@ static float* g_stamp_buf = nullptr;
 extern "C" int case_debug_stamp_buffer(void* p) { g_stamp_buf = (float*)p; return 0; }
 #endif
 
-extern "C" int case_attention_supported(int64_t head_dim) { return head_dim == 64 || head_dim == 96 || head_dim == 320 || head_dim == 480; }
+extern "C" int case_attention_supported(int64_t head_dim) {
+  return head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 160 || head_dim == 320 || head_dim == 480;
+}
 extern "C" int case_attention_bwd_supported(int64_t head_dim) { return case_attention_supported(head_dim); }
 
 #define CASE_ATTN_COMMON_CHECKS(NAME)                                                                                                     \
   CASE_REQUIRE(d->N > 0 && d->heads > 0 && d->Lq > 0 && d->Lk > 0, NAME ": empty problem");                                               \
-  CASE_REQUIRE(case_attention_supported(d->head_dim), NAME ": head_dim %lld not built (64, 96, 320, 480)", (long long)d->head_dim);       \
+  CASE_REQUIRE(case_attention_supported(d->head_dim), NAME ": head_dim %lld not built (32, 64, 96, 160, 320, 480)", (long long)d->head_dim);       \
   CASE_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->sq % 8 == 0 && d->sk % 8 == 0 && d->sv % 8 == 0 &&            \
                    (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0,                                           \
                NAME ": operands must be 16-byte aligned with strides that are multiples of 8 elements");                                  \
@@ -952,8 +959,10 @@ extern "C" int case_attention_fwd(const CaseAttnDesc* d, const void* q, const vo
   a.nblk = (int)nblk;
   hipStream_t s = (hipStream_t)stream;
   switch (d->head_dim) {
+    case 32: return launch_fwd<32>(a, s);
     case 64: return launch_fwd<64>(a, s);
     case 96: return launch_fwd<96>(a, s);
+    case 160: return launch_fwd<160>(a, s);
     case 320: return slab_fits<320>(a) ? launch_fwd_slab<320>(a, s) : launch_fwd<320>(a, s);   // both: 128 queries per workgroup
     default: return launch_fwd<480>(a, s);
   }
@@ -1011,8 +1020,10 @@ extern "C" int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, 
   a.nblk = (int)nblk;
   hipStream_t s = (hipStream_t)stream;
   switch (d->head_dim) {
+    case 32: return launch_fwd_splitkv<32>(a, s);
     case 64: return launch_fwd_splitkv<64>(a, s);
     case 96: return launch_fwd_splitkv<96>(a, s);
+    case 160: return launch_fwd_splitkv<160>(a, s);
     case 320: return launch_fwd_splitkv<320>(a, s);
     default: return launch_fwd_splitkv<480>(a, s);
   }
@@ -1038,8 +1049,10 @@ extern "C" int case_attention_bwd(const CaseAttnDesc* d, const void* q, const vo
   hipStream_t s = (hipStream_t)stream;
   BwdOut g = {(bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv};
   switch (d->head_dim) {
+    case 32: return launch_bwd<32>(a, g, (const bf16_t*)out, delta, s);
     case 64: return launch_bwd<64>(a, g, (const bf16_t*)out, delta, s);
     case 96: return launch_bwd<96>(a, g, (const bf16_t*)out, delta, s);
+    case 160: return launch_bwd<160>(a, g, (const bf16_t*)out, delta, s);
     case 320: return launch_bwd<320>(a, g, (const bf16_t*)out, delta, s);
     default: return launch_bwd<480>(a, g, (const bf16_t*)out, delta, s);
   }

@@ -25,7 +25,15 @@ def _code(t):
         raise TypeError("case_rg_amd: unsupported activation dtype %s" % t.dtype)
 
 
+_raw_stream, _cur_device = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    # the launch stream of every C-ABI call = torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
+    # object behind four layers of Python (9 us per call, ~1900 calls per step: 6 ms of a 29-ms step at the reference's default geometry);
+    # the two C accessors it ends in take 0.3 us
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -807,15 +815,15 @@ def _src_key(t):
 
 # Which attention path runs:
 #   "auto"    per head size, whichever measured faster on MI355X (tools/attn_bench.py, profiles/r02_attn_bench.jsonl):
-#             head_dim 64 / 96 fused forward + backward; head_dim 320 / 480 (the 5H blocks) fused forward only when no
+#             head_dim 32 / 64 / 96 / 160 fused forward + backward; head_dim 320 / 480 (the 5H blocks) fused forward only when no
 #             backward will follow (their fused backward recomputes S in three kernels and is slower than four batched GEMMs
 #             over saved probabilities), otherwise GEMM + softmax + GEMM
-#   "fused"   the fused kernels wherever they are built (64, 96, 320, 480: forward and backward)
+#   "fused"   the fused kernels wherever they are built (32, 64, 96, 160, 320, 480: forward and backward)
 #   "unfused" never fused (tests run the production-shape fixtures under both)
 ATTENTION_MODE = "auto"
 SCORES_FUSED = os.environ.get("CASE_SCORES_FUSED", "1") != "0"  # the GEMM + softmax + GEMM path keeps its scores in the score GEMM's accumulators where K17 covers the shape
-_FUSED_TRAINING = (64, 96)
-_FUSED_INFERENCE = (64, 96, 320)
+_FUSED_TRAINING = (32, 64, 96, 160)   # 32 / 160: hidden 256 (the reference's default), round 5
+_FUSED_INFERENCE = (32, 64, 96, 160, 320)
 # head_dim 320 in INFERENCE where K17 covers the shape (Lk <= 384): "slab" (default) = the fused flash-style forward (fas_fwd_kernel, f32
 # probabilities inside the kernel); "scores" = K17's score kernel + product, what training runs.  A/B at B 256 (the greedy pass's encode
 # phase, two runs each on one box, round 5): 194.0 / 195.0 ms with the slab kernel, 190.2 / 191.0 ms with K17 (+1 % answers/s) -- NOT

@@ -373,7 +373,11 @@ def test_gemm_rejects_bad_arguments():
 @pytest.mark.parametrize("N,h,Lq,Lk,d,causal", [(2, 8, 384, 384, 64, False), (2, 8, 384, 384, 320, False), (3, 8, 40, 40, 64, True),
                                                  (2, 8, 40, 520, 64, False), (2, 2, 200, 333, 320, False),
                                                  (2, 8, 512, 512, 96, False), (2, 4, 512, 512, 480, False), (2, 3, 70, 70, 96, True),
-                                                 (1, 2, 100, 45, 480, False), (1, 8, 40, 4200, 96, False), (2, 2, 33, 2500, 320, False)])
+                                                 (1, 2, 100, 45, 480, False), (1, 8, 40, 4200, 96, False), (2, 2, 33, 2500, 320, False),
+                                                 # the reference's default width 256 (CaSE/Run.py:72-78): head_dim 32 in the H-wide stacks, 160 in the 5H blocks;
+                                                 # passages of 100, queries of 60, answers of 40 (causal), the 1000-token memory
+                                                 (3, 8, 100, 100, 32, False), (2, 8, 40, 40, 32, True), (2, 8, 40, 1000, 32, False), (2, 8, 60, 60, 32, False),
+                                                 (3, 8, 100, 100, 160, False), (2, 8, 60, 60, 160, False), (1, 8, 40, 2100, 32, False), (2, 4, 130, 70, 160, False)])
 def test_fused_attention_matches_unfused_and_reference(N, h, Lq, Lk, d, causal):
     """bf16 fused kernel (no score tensor) vs the f32 reference and vs the unfused GEMM+softmax path, incl. identical
     dropout masks (same counter RNG / element index)."""
