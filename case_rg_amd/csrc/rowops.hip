@@ -423,15 +423,16 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
 // wave per SIMD, 1.7 TB/s.  Here a workgroup of NW waves shares each row: wave w owns columns [512 w, 512 w + 512) (8 per
 // lane), the two row statistics are combined through LDS (R rows per barrier, slots double-buffered -> one barrier per
 // group), and the loads of the next group are requested before the barrier.  ~70 registers, 4+ workgroups per CU.
-template <typename T, int R, bool HAS_X2, bool HAS_ADD, bool DROP2 = false>
-__global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int R, bool HAS_X2, bool HAS_ADD, bool DROP2 = false, typename V = Vec16<T>, int MAXW = 8>
+__global__ __launch_bounds__(64 * MAXW) void ln_bwd_split_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ x2, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            T* __restrict__ dx, const T* __restrict__ dx_add,
                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta, int64_t rows,
                                                            int64_t cols, const LnDrop dr = LnDrop()) {
-  constexpr int E = Vec16<T>::N;
-  __shared__ float part[2][R][8][2];  // [buffer][row of the group][wave][s1, s2]
+  constexpr int E = V::N;
+  typedef typename V::raw raw_t;
+  __shared__ float part[2][R][MAXW][2];  // [buffer][row of the group][wave][s1, s2]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t col = ((int64_t)wid * 64 + lane) * E;  // cols == nw * 64 * E (launcher)
   float ag[E], ab[E], g[E];
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__
     g[e] = gamma[col + e];
   }
   struct Raw {  // the rows stay packed (16 bytes per stream) between the two passes; x^ and dy gamma are recomputed
-    uint4 x[R], d[R], x2[HAS_X2 ? R : 1], add[HAS_ADD ? R : 1];
+    raw_t x[R], d[R], x2[HAS_X2 ? R : 1], add[HAS_ADD ? R : 1];
     float mu[R], rs[R];
   };
   auto request = [&](Raw& w, int64_t row0) {
@@ -451,17 +452,17 @@ __global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__
       const int64_t o = r * cols + col;
       w.mu[j] = mean[r];
       w.rs[j] = rstd[r];
-      w.x[j] = *reinterpret_cast<const uint4*>(x + o);
-      w.d[j] = *reinterpret_cast<const uint4*>(dy + o);
-      if constexpr (HAS_X2) w.x2[j] = *reinterpret_cast<const uint4*>(x2 + o);
-      if constexpr (HAS_ADD) w.add[j] = *reinterpret_cast<const uint4*>(dx_add + o);
+      w.x[j] = *reinterpret_cast<const raw_t*>(x + o);
+      w.d[j] = *reinterpret_cast<const raw_t*>(dy + o);
+      if constexpr (HAS_X2) w.x2[j] = *reinterpret_cast<const raw_t*>(x2 + o);
+      if constexpr (HAS_ADD) w.add[j] = *reinterpret_cast<const raw_t*>(dx_add + o);
     }
   };
   auto normalised = [&](const Raw& w, int j, float (&xh)[E]) {
-    Vec16<T>::unpack(w.x[j], xh);
+    V::unpack(w.x[j], xh);
     if constexpr (HAS_X2) {
       float t[E];
-      Vec16<T>::unpack(w.x2[j], t);
+      V::unpack(w.x2[j], t);
 #pragma unroll
       for (int e = 0; e < E; ++e) xh[e] += t[e];
     }
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__
     for (int j = 0; j < R; ++j) {
       float xh[E], d[E];
       normalised(cur, j, xh);
-      Vec16<T>::unpack(cur.d[j], d);
+      V::unpack(cur.d[j], d);
       float s1 = 0.f, s2 = 0.f;
       const bool real = row0 + j < rows;
 #pragma unroll
@@ -511,17 +512,17 @@ __global__ __launch_bounds__(512) void ln_bwd_split_kernel(const T* __restrict__
       if (row0 + j < rows) {
         float xh[E], d[E], o[E];
         normalised(cur, j, xh);
-        Vec16<T>::unpack(cur.d[j], d);
+        V::unpack(cur.d[j], d);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = cur.rs[j] * (d[e] * g[e] - m1 - xh[e] * m2);
         if constexpr (HAS_ADD) {
           float w[E];
-          Vec16<T>::unpack(cur.add[j], w);
+          V::unpack(cur.add[j], w);
 #pragma unroll
           for (int e = 0; e < E; ++e) o[e] += w[e];
         }
-        Vec16<T>::store(dx + (row0 + j) * cols + col, o);
-        if constexpr (DROP2) ln_store_dropped<T>(dr, (row0 + j) * cols + col, o);
+        V::store(dx + (row0 + j) * cols + col, o);
+        if constexpr (DROP2) ln_store_dropped<T, V>(dr, (row0 + j) * cols + col, o);
       }
     }
     cur = nxt;
@@ -576,6 +577,18 @@ void ln_bwd_vec_launch(const void* dy, const void* x, const void* x2, const floa
       else LN8B(5);
 #undef LN8B
 #undef LN8
+      return;
+    }
+    if (cols % 256 == 0 && cols % 512 != 0 && cols <= 15 * 256) {  // 3840 = cfg 5's 5H rows: the row-split kernel, fifteen waves of 256 columns
+      constexpr int R = 2;
+      const int nw = (int)(cols / 256);
+      const int grid = grid_for(rows, 1, R * 16, 256 * 4);
+#define LNS8(X2, ADD) hipLaunchKernelGGL((ln_bwd_split_kernel<T, R, X2, ADD, false, Vec8<T>, 16>), dim3(grid), dim3(64 * nw), 2 * cols * sizeof(float), s, (const T*)dy, (const T*)x, (const T*)x2, gamma, mean, rstd, (T*)dx, (const T*)dx_add, dg, db, rows, cols)
+      if (x2 && dx_add) LNS8(true, true);
+      else if (x2) LNS8(true, false);
+      else if (dx_add) LNS8(false, true);
+      else LNS8(false, false);
+#undef LNS8
       return;
     }
   }
@@ -955,6 +968,12 @@ bool ln_bwd_drop_launch(const void* dy, const void* x, const float* gamma, const
       else if (cols == 768) LN8D(3);
       else LN8D(5);
 #undef LN8D
+      return true;
+    }
+    if (cols % 256 == 0 && cols % 512 != 0 && cols <= 15 * 256) {
+      constexpr int R = 2;
+      hipLaunchKernelGGL((ln_bwd_split_kernel<T, R, false, false, true, Vec8<T>, 16>), dim3(grid_for(rows, 1, R * 16, 256 * 4)), dim3(64 * (int)(cols / 256)),
+                         2 * cols * sizeof(float), s, (const T*)dy, (const T*)x, nul, gamma, mean, rstd, (T*)dx, nul, dg, db, rows, cols, dr);
       return true;
     }
   }

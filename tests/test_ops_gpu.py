@@ -823,7 +823,7 @@ def test_weight_gradient_gemm_also_sums_the_bias_gradient():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cols_k", [1, 2, 5, 0.5, 1.5, 2.5])
+@pytest.mark.parametrize("cols_k", [1, 2, 5, 0.5, 1.5, 2.5, 7.5])
 def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_for_bit(dt, cols_k):
     """case_layernorm_bwd_dropout: dx and mask * dx / (1 - p) from one kernel == case_layernorm_bwd followed by case_dropout (same bits:
     the mask is applied to the rounded dx), for the one-wave-per-row kernels (k = 1, 2) and the row-split kernel (k = 5: the 5H rows)."""
@@ -831,7 +831,7 @@ def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_
     from case_rg_amd import _abi as A
     if dt == torch.float32 and cols_k != int(cols_k):
         pytest.skip("the 8-byte-vector rows are a bf16 form")
-    rows, cols = 77, int(cols_k * (256 if dt == torch.float32 else 512))  # bf16 x 0.5 / 1.5 / 2.5 = 256 / 768 / 1280: the 8-byte-vector kernels
+    rows, cols = 77, int(cols_k * (256 if dt == torch.float32 else 512))  # bf16 x 0.5 / 1.5 / 2.5 / 7.5 = 256 / 768 / 1280 / 3840: the 8-byte-vector kernels
     x, dy = _rand(rows, cols, dt=dt, seed=1), _rand(rows, cols, dt=dt, seed=2)
     gamma = _rand(cols, seed=3) + 1.0
     mean, rstd = x.float().mean(1).contiguous(), (x.float().var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
