@@ -595,6 +595,41 @@ def case_prod_masque_train_p10(ns, dev):
     return rec
 
 
+# The reference's OWN default geometry (CaSE/Run.py:72-78: hidden 256 -> 8 heads of 32 in the H-wide stacks, 160 in the 5H blocks;
+# Prepare_dataset.py:13-17: queries of 60, ten passages of 100, answers of 40): what a user who drops this package into Run.py unchanged
+# runs.  Two items, ragged lengths, one filler passage.  On the GPU these are the shapes of the head_dim 32 / 160 fused attention kernels
+# and of the 256- / 1280-column LayerNorm backward kernels added late in round 5; ~15 s per model on the build container's CPU.
+def _refdef_batch(dev, seed, model):
+    b = synth_batch(2, 10, 100, 60, 40, PROD_V, seed=seed, model=model)
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def _refdef_model(ns, dev, seed, model):
+    v2i, i2v = make_vocab(PROD_V)
+    m = ns.CaSE(4, 40, i2v, v2i, 256) if model == "case" else ns.Masque(40, i2v, v2i, 256)
+    return _mod(m, seed, dev)
+
+
+def case_refdef_case_train(ns, dev):
+    m = _refdef_model(ns, dev, 271, "case")
+    b = _refdef_batch(dev, 272, "case")
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_se": losses[1].reshape(1), "loss_rg": losses[2].reshape(1)})
+    rec.update(_model_grads(m, losses, CASE_GRAD_NAMES, strided=True))
+    return rec
+
+
+def case_refdef_masque_train(ns, dev):
+    m = _refdef_model(ns, dev, 281, "masque")
+    b = _refdef_batch(dev, 282, "masque")
+    rec = _prod_record(b)
+    losses = m(dict(b), method="train")
+    rec.update({"loss_ps": losses[0].reshape(1), "loss_rg": losses[1].reshape(1)})
+    rec.update(_model_grads(m, losses, MASQUE_GRAD_NAMES, strided=True))
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------
 # greedy decoding at PRODUCTION geometry (BASELINE cfg 4 shapes per item: H 512, 8 heads of 64, Lp 384, Lq 64, V 30522): the
 # reference's own O(T^2) loop (CaSE/Model.py:91-123, Masque/Model.py:85-117) on two queries x two passages, T = 14 steps.  On
@@ -754,6 +789,6 @@ def case_cfg5_masque_train(ns, dev):
 CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("case_")}
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
 PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory", "cfg5_case_train",
-              "cfg5_masque_train", "prod_case_train_p10", "prod_masque_train_p10")
+              "cfg5_masque_train", "prod_case_train_p10", "prod_masque_train_p10", "refdef_case_train", "refdef_masque_train")
 PROD_TEST_CASES = ("prod_case_test", "prod_masque_test")  # greedy decoding at production geometry
 PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too
