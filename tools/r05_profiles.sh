@@ -1,4 +1,5 @@
-# Round-5 evidence run (GPU box): bash tools/r05_profiles.sh  -> gpurun_out/r05z/*  (copy what is judged into profiles/r05_*)
+# Round-5 evidence run (GPU box): bash tools/r05_profiles.sh [a|b|all]  -> gpurun_out/r05z/*  (copy what is judged into profiles/r05_*)
+# a = the default command's kernel table + PMC passes, b = the other modes (each half fits one 20-minute gpurun call)
 # Every rocprofv3 command has the program itself (python3 ...) directly after `--`; counters are collected in their own passes.
 set -e
 cd /tmp && export TMPDIR=/tmp
@@ -6,6 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05z
 mkdir -p $O
 cd $R
+PART=${1:-all}
+if [ "$PART" != b ]; then
 # 1. the default bench command under kernel-trace stats, and without the profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_stats.err
 cp $(find $O/stats -name 's_kernel_stats.csv') $O/bench_kernel_stats.csv; rm -rf $O/stats
@@ -43,6 +46,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_dw -o w 
 python3 tools/pmc_traffic.py $(find $O/pmc_df -name 'f_counter_collection.csv') $(find $O/pmc_dw -name 'w_counter_collection.csv') $O/dec_pmc_traffic.json "$WD" "$CD" > $O/dec_pmc_traffic.txt
 rm -rf $O/pmc_df $O/pmc_dw
 echo dec pmc done
+fi
+if [ "$PART" != a ]; then
 # 4. the other modes
 python3 bench.py --mode decode --batch 256 > $O/dec.json 2> $O/dec.err
 python3 bench.py --mode decode --batch 256 --graph --no-cpu-baseline > $O/dec_graph.json 2> $O/dec_graph.err
@@ -54,4 +59,5 @@ python3 bench.py --mode refdefault > $O/refdefault.json 2> $O/refdefault.err
 python3 bench.py --mode encoder --batch 64 --enc-layers 3 > $O/enc3.json 2> $O/enc3.err
 python3 bench.py --mode encoder --batch 64 > $O/enc6.json 2> $O/enc6.err
 echo modes done
+fi
 ls -la $O
