@@ -645,13 +645,13 @@ def _prod_test_batch(dev, seed, model):
     return {k: v.to(dev) for k, v in b.items()}
 
 
-def _prod_test_model(ns, dev, seed, model, gain):
+def _prod_test_model(ns, dev, seed, model, gain, hidden=512):
     """``gain`` = (global weight gain, extra gain on the pointer heads' ``v`` vectors, extra gain on the vocabulary projection).
     A large GLOBAL gain makes a 20-layer random network chaotic (f32 op-order differences reach 1e-3 on the rank logits at
     gain 7), so the decisiveness comes from the last linear maps in front of the softmaxes instead: errors upstream are not
     amplified through the depth of the network, only scaled once."""
     v2i, i2v = make_vocab(PROD_V)
-    m = ns.CaSE(4, PROD_T, i2v, v2i, 512) if model == "case" else ns.Masque(PROD_T, i2v, v2i, 512)
+    m = ns.CaSE(4, PROD_T, i2v, v2i, hidden) if model == "case" else ns.Masque(PROD_T, i2v, v2i, hidden)
     m = _mod(m, seed, dev, gain=gain[0])
     with torch.no_grad():
         for n, p in m.named_parameters():
@@ -668,9 +668,7 @@ def _top2(dist):
     return top[0][..., 0] - top[0][..., 1], top[0][..., 0], top[1][..., 0]
 
 
-def case_prod_case_test(ns, dev):
-    m = _prod_test_model(ns, dev, 311, "case", PROD_TEST_GAIN["case"])
-    b = _prod_test_batch(dev, 312, "case")
+def _case_test_record(ns, m, b):
     out = _greedy(m, b)
     rec = {"in_" + k: v for k, v in b.items() if k in ("query", "passage", "source_map")}
     rec.update({"answer": out["answer"], "rank": out["rank"]})
@@ -686,9 +684,11 @@ def case_prod_case_test(ns, dev):
     return rec
 
 
-def case_prod_masque_test(ns, dev):
-    m = _prod_test_model(ns, dev, 321, "masque", PROD_TEST_GAIN["masque"])
-    b = _prod_test_batch(dev, 322, "masque")
+def case_prod_case_test(ns, dev):
+    return _case_test_record(ns, _prod_test_model(ns, dev, 311, "case", PROD_TEST_GAIN["case"]), _prod_test_batch(dev, 312, "case"))
+
+
+def _masque_test_record(ns, m, b):
     out = _greedy(m, b)
     rec = {"in_" + k: v for k, v in b.items() if k in ("query", "passage", "source_map")}
     rec.update({"answer": out["answer"], "rank": out["rank"]})
@@ -701,6 +701,25 @@ def case_prod_masque_test(ns, dev):
                                           passage_selection_result=ps, output=out["answer"])
         rec["margin"], rec["top1_prob"], rec["top1_id"] = _top2(rg[2])
     return rec
+
+
+def case_prod_masque_test(ns, dev):
+    return _masque_test_record(ns, _prod_test_model(ns, dev, 321, "masque", PROD_TEST_GAIN["masque"]), _prod_test_batch(dev, 322, "masque"))
+
+
+# greedy decoding at the reference's DEFAULT geometry (hidden 256, ten passages of 100, queries of 60): the decode path outside the
+# width-512 kernels (K13 at head_dim 64, K16, K21 - K23 are 512-wide) -- what do_test runs when the package is dropped into Run.py unchanged
+def _refdef_test_batch(dev, seed, model):
+    b = synth_batch(2, 10, 100, 60, PROD_T, PROD_V, seed=seed, model=model)
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def case_refdef_case_test(ns, dev):
+    return _case_test_record(ns, _prod_test_model(ns, dev, 331, "case", PROD_TEST_GAIN["case"], hidden=256), _refdef_test_batch(dev, 332, "case"))
+
+
+def case_refdef_masque_test(ns, dev):
+    return _masque_test_record(ns, _prod_test_model(ns, dev, 341, "masque", PROD_TEST_GAIN["masque"], hidden=256), _refdef_test_batch(dev, 342, "masque"))
 
 
 # (global, pointer-head v, vocabulary projection) gains, scanned in the build container.  Global gains of 5-10 give answers with
@@ -790,5 +809,5 @@ CASES = {f[5:]: f_obj for f, f_obj in list(globals().items()) if f.startswith("c
 MODEL_CASES = ("case_train", "case_test", "masque_train", "masque_test")
 PROD_CASES = ("prod_case_train", "prod_masque_train", "cfg5_block_5h", "cfg5_block_h", "cfg5_dec_layer_long_memory", "cfg5_case_train",
               "cfg5_masque_train", "prod_case_train_p10", "prod_masque_train_p10", "refdef_case_train", "refdef_masque_train")
-PROD_TEST_CASES = ("prod_case_test", "prod_masque_test")  # greedy decoding at production geometry
+PROD_TEST_CASES = ("prod_case_test", "prod_masque_test", "refdef_case_test", "refdef_masque_test")  # greedy decoding at production geometry / the reference's defaults
 PROD_FORWARD_CASES = ("prod_enc_layer", "prod_block_5h")  # older forward-only fixtures, replayed in the bf16 modes too

