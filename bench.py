@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-north-star", action="store_true", help="skip the encoder-forward point appended to the default line")
     ap.add_argument("--no-decode-point", action="store_true", help="skip the greedy-decode point (cfg 4) appended to the default line")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: the BASELINE workload keeps dropout on")
+    ap.add_argument("--ragged", action="store_true", help="diagnostic only: sequences of random length (half .. full) + one filler passage per item, as the "
+                                                          "parity fixtures have them; the BASELINE workload is full-length (every row is a token)")
     ap.add_argument("--model", default="case", choices=["case", "masque"])
     ap.add_argument("--mode", default="train", choices=["train", "decode", "encoder", "cfg5", "refdefault"],
                     help="train: tokens/s of the training step (default, BASELINE cfg 2); decode: greedy answers/s (cfg 4); "
@@ -133,7 +135,7 @@ def build(a, device):
     sched = get_cosine_with_hard_restarts_schedule_with_warmup(opt, 2000, 100000)
     rank = dist.get_rank() if dist.is_initialized() else 0
     batch = synth_batch(a.batch, a.passages, a.passage_len, a.query_len, a.answer_len, a.vocab, seed=123456 + rank,
-                        ragged=False, model=a.model)
+                        ragged=bool(getattr(a, "ragged", False)), model=a.model)
     batch = {k: v.to(device) for k, v in batch.items()}
     trainer.model.train()
     return trainer, opt, sched, batch
@@ -636,7 +638,8 @@ def main():
         "config": {"workload": "%s train step fwd+bwd+allreduce+clip+Adam+EMA, d_model=%d, %d encoder layers, %d passages x %d tok, "
                                "query %d, answer %d, vocab %d, per-GPU batch %d, dropout %s" % (
                                    "CaSE" if a.model == "case" else "Masque", a.hidden, a.enc_layers, a.passages, a.passage_len,
-                                   a.query_len, a.answer_len, a.vocab, a.batch, "off (diagnostic)" if a.no_dropout else "on"),
+                                   a.query_len, a.answer_len, a.vocab, a.batch, ("off (diagnostic)" if a.no_dropout else "on") +
+                                   (", RAGGED lengths (diagnostic: padding is counted as tokens)" if getattr(a, "ragged", False) else "")),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                    "algorithmic_tflop_per_step": round(3 * fwd * world / 1e12, 2)},
         "step_mfma_frac": round(3 * fwd / (elapsed / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
