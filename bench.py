@@ -148,16 +148,16 @@ def workload_key(a):
 
 def pmc_traffic(kernel_key, workload, pattern="*_pmc_traffic.json"):
     """ARCHIVED HBM bytes per launch of ``kernel_key``: the newest committed PMC summary (profiles/*_pmc_traffic.json, made by
-    tools/pmc_traffic.py from two rocprofv3 --pmc passes, see tools/r05_pmc.sh) whose ``workload`` equals this run's; files written
-    before round 5 carry no key and were all measured on the default CaSE cfg 2 line.  (None, None) when there is none: a PMC
-    number of another model / batch is never printed beside this run's timings."""
+    tools/pmc_traffic.py from two rocprofv3 --pmc passes, see tools/r06_profiles.sh) whose ``workload`` equals this run's; files written
+    before round 5 carry no key and are skipped (what they were measured on is not recorded in them).  (None, None) when there is
+    none: a PMC number of another model / batch is never printed beside this run's timings."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
     for path in reversed(sorted(glob.glob(os.path.join(here, "profiles", pattern)))):
         try:
             with open(path) as fh:
                 rec = json.load(fh)
-            if rec.get("workload", "case/b32/h512/p10x384/enc6/bf16") != workload:
+            if rec.get("workload") != workload:
                 continue
             k = rec["kernels"].get(kernel_key)
             if k:
@@ -248,7 +248,7 @@ def roofline_cross_attention(a, device):
         torch.cuda.synchronize()
     secs = e0.elapsed_time(e1) / iters * 1e-3
     nbytes = N * S * 2 * E * 2
-    # ARCHIVED PMC bytes of the split-KV forward launch alone (tools/cfg5_stream.py under two rocprofv3 passes: tools/r05_pmc.sh)
+    # ARCHIVED PMC bytes of the split-KV forward launch alone (tools/cfg5_stream.py under two rocprofv3 passes: tools/r05_profiles.sh)
     traffic, traffic_src = pmc_traffic("fa_fwd_kernel", workload_key(a), "*_cfg5stream_pmc.json")
     return {"bound": "hbm", "kernel": "fa_fwd_kernel<96, split-KV> + fa_combine_kernel<96> (decoder cross-attention, S = %d)" % S,
             "achieved": round(nbytes / secs / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / secs / 8e12, 4),
@@ -602,6 +602,8 @@ def main():
         one = torch.ones(1, device=device)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         ranks_seen = int(round(float(one.item())))
+        if ranks_seen != max(1, a.gpus):  # a run mislabelled as N GPUs must not print a line
+            raise SystemExit("bench.py --gpus %d: the all-reduce over the process group saw %d rank(s)" % (a.gpus, ranks_seen))
 
     def step():
         return trainer.train_batch(0, dict(batch), "train", opt, sched)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CASE_HIP_LIB: another build of the same library (A/B measurements of kernel variants); there is still no non-HIP path
 LIB_PATH = os.environ.get("CASE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcase_hip.so")
 
-ABI_VERSION = 500  # include/case_hip.h CASE_ABI_VERSION this binding was written against
+ABI_VERSION = 600  # include/case_hip.h CASE_ABI_VERSION this binding was written against
 F32, BF16 = 0, 1
 WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
 (FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
@@ -27,7 +27,12 @@ class GemmDesc(C.Structure):
     _fields_ = [(n, i64) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ld_aux", "batch1", "batch2",
                                    "sa1", "sa2", "sb1", "sb2", "sc1", "sc2", "saux1", "saux2")] + \
                [(n, i32) for n in ("a_kmajor", "b_kmajor", "in_dtype", "out_dtype", "epilogue", "split_k", "tile")] + \
-               [("alpha", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
+               [("alpha", f32), ("drop_p", f32), ("seed", u64), ("offset", u64), ("state", ptr)]
+
+
+class StepState(C.Structure):
+    """CaseStepState: the per-step scalars in caller-owned DEVICE memory (ABI 600) -- see include/case_hip.h."""
+    _fields_ = [("rng_base", u64), ("step_size", f32), ("bc2_sqrt", f32), ("lr", f32), ("step", i32), ("reserved", u64 * 5)]
 
 
 class EncoderChainDesc(C.Structure):
@@ -36,12 +41,12 @@ class EncoderChainDesc(C.Structure):
 
 class SoftmaxDesc(C.Structure):
     _fields_ = [("outer", i64), ("inner", i64), ("R", i64), ("C", i64), ("causal", i32), ("in_dtype", i32),
-                ("out_dtype", i32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
+                ("out_dtype", i32), ("drop_p", f32), ("seed", u64), ("offset", u64), ("state", ptr)]
 
 
 class AttnDesc(C.Structure):
     _fields_ = [(n, i64) for n in ("N", "heads", "Lq", "Lk", "head_dim", "ldq", "ldk", "ldv", "sq", "sk", "sv", "ldo", "so")] + \
-               [("causal", i32), ("scale", f32), ("drop_p", f32), ("seed", u64), ("offset", u64)]
+               [("causal", i32), ("scale", f32), ("drop_p", f32), ("seed", u64), ("offset", u64), ("state", ptr)]
 
 
 class AttnProductDesc(C.Structure):
@@ -54,12 +59,12 @@ SIGNATURES = {
     "case_gemm": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_gemm_dw_bias": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr],
     "case_gemm_dw_slabs": [C.POINTER(GemmDesc), ptr, ptr, ptr, ptr, ptr, i64, ptr],
-    "case_embed_pos_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
-    "case_embed_pos_bwd": [ptr, ptr, ptr, i64, i64, i64, f32, f32, u64, u64, i32, ptr],
+    "case_embed_pos_fwd": [ptr, ptr, ptr, ptr, i64, i64, i64, i64, f32, f32, u64, u64, ptr, i32, ptr],
+    "case_embed_pos_bwd": [ptr, ptr, ptr, i64, i64, i64, f32, f32, u64, u64, ptr, i32, ptr],
     "case_scale_add_rows": [ptr, ptr, ptr, i64, i64, i64, f32, i32, ptr],
     "case_layernorm_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, f32, i32, ptr],
     "case_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
-    "case_layernorm_bwd_dropout": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, f32, u64, u64, i32, ptr],
+    "case_layernorm_bwd_dropout": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, f32, u64, u64, ptr, i32, ptr],
     "case_layernorm_bwd_concat5": [ptr] * 15 + [i64, i64, i32, ptr],
     "case_softmax_fwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr, ptr, ptr],
     "case_softmax_bwd": [C.POINTER(SoftmaxDesc), ptr, ptr, ptr, ptr],
@@ -78,7 +83,7 @@ SIGNATURES = {
     "case_attention_product": [C.POINTER(AttnProductDesc), ptr, ptr, ptr, ptr],
     "case_add": [ptr, ptr, ptr, i64, i32, ptr],
     "case_add_n": [C.POINTER(ptr), i32, ptr, i64, i32, ptr],
-    "case_dropout": [ptr, ptr, i64, f32, u64, u64, i32, ptr],
+    "case_dropout": [ptr, ptr, i64, f32, u64, u64, ptr, i32, ptr],
     "case_mask_rows": [ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_colsum": [ptr, ptr, i64, i64, i32, ptr],
     "case_cast": [ptr, ptr, i64, i32, i32, ptr],
@@ -113,7 +118,8 @@ SIGNATURES = {
     "case_pointer_head_decode": [ptr] * 5 + [i32] + [ptr] * 4 + [i64, i64, i64, ptr],
     "case_gemm_ln": [C.POINTER(GemmDesc), ptr, ptr, ptr, f32, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
-    "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr],
+    "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr, ptr],
+    "case_step_advance": [ptr, u64, f64, f64, ptr],
 }
 
 
@@ -148,6 +154,10 @@ def _load():
     lib.case_get_reserved_cus.argtypes = []
     lib.case_sizeof_opt_tensor.restype = C.c_int
     lib.case_sizeof_opt_tensor.argtypes = []
+    lib.case_sizeof_step_state.restype = C.c_int
+    lib.case_sizeof_step_state.argtypes = []
+    if lib.case_sizeof_step_state() != C.sizeof(StepState):
+        raise ImportError("case_rg_amd: CaseStepState is %d bytes in %s, %d in this binding" % (lib.case_sizeof_step_state(), LIB_PATH, C.sizeof(StepState)))
     lib.case_gemm_dw_slab_bytes.restype = C.c_int64
     lib.case_gemm_dw_slab_bytes.argtypes = [C.POINTER(GemmDesc)]
     lib.case_workspace_bytes.restype = C.c_int64

@@ -40,7 +40,10 @@ def init_params(model, escape=None):
 
 
 class CumulativeTrainer(object):
-    def __init__(self, model, tokenizer, detokenizer, local_rank, num_gpus, accumulation_steps=1, ema_rate=0.995):
+    def __init__(self, model, tokenizer, detokenizer, local_rank, num_gpus, accumulation_steps=1, ema_rate=0.995, capture=None):
+        """``capture`` (not in the reference; default: environment CASE_STEP_GRAPH=1): replay the training step from a hipGraph
+        recorded after two eager steps per batch shape (``case_rg_amd.stepgraph``) -- for the geometries whose step is launch-bound
+        (the reference's default: hidden 256, batch 16).  The per-step scalars then live in device memory (``self.step_state``)."""
         self.local_rank = local_rank
         self.num_gpus = num_gpus
         self.tokenizer = tokenizer
@@ -56,20 +59,55 @@ class CumulativeTrainer(object):
         self.ema = EMA(self.model, ema_rate)
         self.ema.register()
         self._loss_host = None
+        if capture is None:
+            capture = os.environ.get("CASE_STEP_GRAPH", "0") == "1"
+        self.step_state, self.graphs = None, None
+        if capture and torch.cuda.is_available():
+            from ..stepgraph import StepGraphs
+            from ..stepstate import StepState
+            self.step_state = StepState(next(self.model.parameters()).device)
+            config.set_device_state(self.step_state.address)  # every dropout site from here on adds the device-resident base
+            self.graphs = StepGraphs(self)
+
+    def close(self):
+        """Detach the device-resident step state from the process-wide dropout configuration (a capturing trainer owns it)."""
+        if self.step_state is not None and config.device_state() == self.step_state.address:
+            config.set_device_state(None)
+        self.step_state, self.graphs = None, None
 
     def train_batch(self, epoch, data, method, optimizer, scheduler=None):
         try:
             return self._train_batch(epoch, data, method, optimizer, scheduler)
-        except BaseException:
-            if self.sync is not None:  # the step died between backward and finish(): release what GradSync holds (reserved CUs, buckets)
-                self.sync.abort()
+        except Exception:
+            # the step died between backward and finish(): release what GradSync holds (reserved CUs, bucket counters).  Only for ordinary
+            # exceptions -- a KeyboardInterrupt / SystemExit must not wait on collectives whose peers may be gone -- and a failure inside
+            # abort() is reported but never replaces the error that ended the step.  Recovery after a ONE-rank failure is not supported:
+            # the other ranks are blocked in their collectives until the process group's timeout.
+            if self.sync is not None:
+                try:
+                    self.sync.abort()
+                except Exception as cleanup:  # noqa: BLE001
+                    print("CumulativeTrainer: GradSync.abort() failed while handling the step's error: %r" % (cleanup,), file=sys.stderr)
             raise
 
     def _train_batch(self, epoch, data, method, optimizer, scheduler=None):
+        if self.graphs is not None:
+            losses = self.graphs.run(epoch, data, method, optimizer, scheduler)
+            if losses is not None:
+                self.accumulation_count += 1
+                return losses
         self.accumulation_count += 1
         boundary = self.accumulation_count % self.accumulation_steps == 0
         if self.sync is not None:
             self.sync.no_sync(not boundary)
+        state = self.step_state if isinstance(optimizer, FusedAdam) else None
+        if self.step_state is not None:
+            # device-resident step scalars: the dropout sites of this step are numbered from 0 and add the base uploaded here -- the
+            # same numbering a replayed capture of the step uses
+            base = config.begin_step()
+            if state is not None and boundary:
+                optimizer.stage_step(state)
+            self.step_state.upload(base)
         loss = self.model(data, method=method)
         if isinstance(loss, (tuple, list)):
             parts = torch.cat([l.mean().reshape(1) for l in loss])
@@ -80,9 +118,9 @@ class CumulativeTrainer(object):
         # optimizer kernels are enqueued (round 3 drained the device here, in the middle of the step, before enqueueing them)
         host, done = None, None
         if parts.is_cuda:
-            if self._loss_host is None or self._loss_host.numel() != parts.numel():
-                self._loss_host = torch.empty(parts.numel(), dtype=torch.float32).pin_memory()
-            host = self._loss_host
+            if self._loss_host is None or self._loss_host.numel() < parts.numel():
+                self._loss_host = torch.empty(max(8, parts.numel()), dtype=torch.float32).pin_memory()
+            host = self._loss_host[:parts.numel()]
             host.copy_(parts.detach().float(), non_blocking=True)
             done = torch.cuda.Event()
             done.record()
@@ -90,7 +128,7 @@ class CumulativeTrainer(object):
             if self.sync is not None:
                 self.sync.finish()
             if isinstance(optimizer, FusedAdam):  # clip + Adam + EMA + bf16 operand refresh in one multi-tensor pass (K15)
-                optimizer.step(clip_norm=1.0, ema=self.ema)
+                optimizer.step(clip_norm=1.0, ema=self.ema, state=state)
             else:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1)
                 optimizer.step()
@@ -150,6 +188,8 @@ class CumulativeTrainer(object):
         if state['rng']['cuda'] is not None and torch.cuda.is_available():
             torch.cuda.set_rng_state(state['rng']['cuda'].cpu())
         config.set_rng_state(state['rng']['dropout_counter'])
+        if self.graphs is not None:
+            self.graphs.reset()  # the captures read tensors this load replaced (EMA shadows, optimizer moments)
         ops.invalidate_param_cache()  # load_state_dict copies in place under no_grad: cached bf16 operand copies are stale
         return state['epoch']
 

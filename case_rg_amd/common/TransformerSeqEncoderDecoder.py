@@ -161,7 +161,10 @@ class PointerDecoderCore(nn.Module):
         the additive-attention keys are cached, so a step streams the caches once instead of recomputing the prefix
         (O(T) instead of O(T^2) decoder work, no per-step projection of the 3840-token passage memory)."""
         B, dev = mems[0].shape[0], mems[0].device
-        cache = self._memory_cache(mems, absorb=not self.training)
+        # the raw-pointer decode kernels (K21 / K22 / K23) have no autograd Function behind them: eval mode AND no_grad (the reference only
+        # predicts under no_grad; a caller that differentiates an eval-mode greedy pass keeps the differentiable launches)
+        inference = not self.training and not torch.is_grad_enabled()
+        cache = self._memory_cache(mems, absorb=inference)
         self_kvs = [dec.new_self_cache(B, max_target_length, mems[0]) for dec in self.decs]
         hist_valid = torch.zeros(B, max_target_length, dtype=torch.bool, device=dev)
         table, pos = self.embedding[0].weight, self.embedding[1]
@@ -172,7 +175,7 @@ class PointerDecoderCore(nn.Module):
         picked = []
         finished = None if self.eos_id is None else torch.zeros(B, dtype=torch.bool, device=dev)
         capturing = torch.cuda.is_current_stream_capturing()  # a captured pass cannot branch on device data: fixed T steps
-        fused_head = (not self.training and hasattr(self, "_head_parts") and ops.pointer_head_supported(source_map, self.tgt_vocab_size, len(mems)))
+        fused_head = (inference and hasattr(self, "_head_parts") and ops.pointer_head_supported(source_map, self.tgt_vocab_size, len(mems)))
         for t in range(max_target_length):
             tok_valid = ids.ne(0)
             hist_valid[:, t] = tok_valid[:, 0]

@@ -13,7 +13,7 @@ dropout
 """
 import torch
 
-_state = {"dtype": torch.float32, "dropout": True, "seed": 123456, "offset": 0}
+_state = {"dtype": torch.float32, "dropout": True, "seed": 123456, "offset": 0, "base": 0, "device_state": None}
 
 
 def set_compute_dtype(dtype):
@@ -36,23 +36,60 @@ def dropout_enabled():
 
 def manual_seed(seed):
     _state["seed"] = int(seed) & 0x7FFFFFFFFFFFFFFF
-    _state["offset"] = 0
+    _state["offset"], _state["base"] = 0, 0
 
 
 def rng_state():
-    """(seed, offset) of the dropout counter stream -- what a resumable checkpoint stores."""
-    return _state["seed"], _state["offset"]
+    """(seed, position) of the dropout counter stream -- what a resumable checkpoint stores.  The position is ``base + offset``: with a
+    device state the sites of a step are numbered from ``offset`` 0 and ``base`` (the sum of the earlier steps' consumption) is what the
+    kernels read from the device; without one ``base`` stays 0."""
+    return _state["seed"], _state["base"] + _state["offset"]
 
 
 def set_rng_state(state):
-    _state["seed"], _state["offset"] = int(state[0]), int(state[1])
+    _state["seed"] = int(state[0])
+    if _state["device_state"] is None:
+        _state["offset"], _state["base"] = int(state[1]), 0
+    else:
+        _state["offset"], _state["base"] = 0, int(state[1])
+
+
+def begin_step():
+    """Device-state mode, once per training step before any dropout site is numbered: fold the previous step's consumption into the
+    base and restart the site offsets at 0; returns the base to upload (CaseStepState.rng_base)."""
+    _state["base"] += _state["offset"]
+    _state["offset"] = 0
+    return _state["base"]
+
+
+def skip_rng(numel):
+    """Account for ``numel`` counters consumed without passing through ``next_rng`` (a replayed hipGraph of a captured step)."""
+    _state["offset"] += int(numel)
 
 
 def next_rng(numel):
-    """Reserve ``numel`` counters; returns (seed, offset) for one dropout site."""
+    """Reserve ``numel`` counters; returns (seed, offset, state) for one dropout site.  ``state`` is None, or the address of the
+    CaseStepState (device memory, ABI 600) whose ``rng_base`` every kernel of the site adds to ``offset`` when it RUNS: with a device
+    state the sites of one step are numbered from 0 (``begin_step``) and the step's base is data on the device, so a hipGraph-captured
+    step draws new masks on every replay (``case_rg_amd.stepstate``)."""
     off = _state["offset"]
     _state["offset"] = off + int(numel) + (int(numel) & 1)  # keep offsets even: the kernels hash element pairs
-    return _state["seed"], off
+    return _state["seed"], off, _state["device_state"]
+
+
+def set_device_state(address):
+    """Address of the CaseStepState the dropout sites read their per-step base from (None: arguments only, the round-5 behaviour).
+    The stream position is kept: switching modes moves it between ``offset`` and ``base``."""
+    pos = _state["base"] + _state["offset"]
+    _state["device_state"] = None if not address else int(address)
+    if _state["device_state"] is None:
+        _state["offset"], _state["base"] = pos, 0
+    else:
+        _state["offset"], _state["base"] = 0, pos
+
+
+def device_state():
+    return _state["device_state"]
 
 
 def drop_p(p, training):

@@ -64,6 +64,7 @@ struct FaArgs {
   int Lq, Lk, heads, causal, nblk, tiles, N;
   float scale, drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state;                          // nullable: offset += state->rng_base (ABI 600)
 };
 
 // Diagnostic builds (-DFAS_STAMPS): wave 0 lane 0 of every workgroup writes s_memtime stamps to the buffer given to
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * NS * NQ, MINW) void fa_fwd_kernel(const FaArgs
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const float scale2 = a.scale * LOG2E;
   const uint32_t thr = rng_threshold(a.drop_p);
-  const uint32_t row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi));
+  const uint32_t row_key = rng_row_key(a.seed, a.offset + rng_base_of(a.state) + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi));
   FAS_STAMP(1);
 
   for (int t = 0; t < ntiles; ++t) {
@@ -533,7 +534,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const FaArgs& a, const BwdOut& g,
   if (a.causal) ntiles = min(ntiles, (min(a.Lq, qt * (32 * NQ) + 32 * NQ) - 1) / TS + 1);
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const uint32_t thr = rng_threshold(a.drop_p);
-  const uint32_t row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi));
+  const uint32_t row_key = rng_row_key(a.seed, a.offset + rng_base_of(a.state) + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq + qi));
   Stage<D, TS, NT> sk, sv;
   RowMask rm;
   sk.init(a.ldk);
@@ -646,7 +647,7 @@ __device__ __forceinline__ void fa_bwd_dkv_body(const FaArgs& a, const BwdOut& g
   const int tbegin = a.causal ? (ktile * (32 * NQ)) / TS : 0;  // queries before the first key of this workgroup see none of its keys
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const uint32_t thr = rng_threshold(a.drop_p);
-  const uint64_t rng_row0 = a.offset + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq);
+  const uint64_t rng_row0 = a.offset + rng_base_of(a.state) + (uint64_t)(((int64_t)n * a.heads + head) * a.Lq);
   const uint32_t jc1 = ((uint32_t)ki >> 1) * RNG_C1, field_shift = 16u * ((uint32_t)ki & 1u);  // this lane's column of the P matrix
   const float scale2 = a.scale * LOG2E;
   const float* lse_g = a.lse + ((int64_t)n * a.heads + head) * a.Lq;
@@ -875,7 +876,7 @@ int fill_args(FaArgs& a, const CaseAttnDesc* d, const void* q, const void* k, co
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv;
   a.key_valid = key_valid;
   a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.heads = (int)d->heads; a.N = (int)d->N; a.causal = d->causal;
-  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset; a.state = d->state;
   return 0;
 }
 

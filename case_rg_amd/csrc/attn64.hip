@@ -66,6 +66,7 @@ struct Args {
   int N, heads, Lq, Lk, nitems;
   float scale, drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state;  // nullable: offset += state->rng_base (ABI 600)
 };
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(NTHR) void fwd_kernel(const Args a) {
       for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qb + roff[s]);
       m = -INFINITY;
       lsum = 0.f;
-      if (DROP) row_key = rng_row_key(a.seed, a.offset + (uint64_t)(((int64_t)my_n * a.heads + my_head) * a.Lq + qi));
+      if (DROP) row_key = rng_row_key(a.seed, a.offset + rng_base_of(a.state) + (uint64_t)(((int64_t)my_n * a.heads + my_head) * a.Lq + qi));
       // every key of the item valid?  (bytes beyond Lk were written as zeros)
       if (masked) {
         int lane_ = l;
@@ -536,7 +537,7 @@ int launch_fwd(const CaseAttnDesc* d, const void* q, const void* k, const void* 
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.sq = d->sq; a.sk = d->sk; a.sv = d->sv;
   a.o = (bf16_t*)out; a.ldo = d->ldo; a.so = d->so; a.lse = lse; a.key_valid = key_valid;
   a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.nitems = (int)(d->N * d->heads);
-  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset; a.state = d->state;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
@@ -586,6 +587,7 @@ struct BArgs {
   int N, heads, Lq, Lk, nitems, ntiles;
   float scale, drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state;  // nullable: offset += state->rng_base (ABI 600)
 };
 
 __device__ __forceinline__ int swz(int row) {  // f((row >> 1) & 7)
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const BArgs a) {
         n_cur += 2;
       } else if (DROP && wave == 9) {  // the dropout row keys of the tile's queries
         if (l < 32) {
-          const uint32_t rk = rng_row_key(a.seed, a.offset + (soff >> 2) + (uint64_t)(dtile * TQ + l));
+          const uint32_t rk = rng_row_key(a.seed, a.offset + rng_base_of(a.state) + (soff >> 2) + (uint64_t)(dtile * TQ + l));
           *reinterpret_cast<uint32_t*>(smem + RING_OFF + sl * SLOT_B + SL_RK + 4 * l) = rk;
         }
       }
@@ -1016,7 +1018,7 @@ int launch(const CaseAttnDesc* d, const void* q, const void* k, const void* v, c
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.nitems = (int)(d->N * d->heads);
   a.ntiles = (int)((d->Lq + TQ - 1) / TQ);
-  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  a.scale = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset; a.state = d->state;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess ||

@@ -56,6 +56,7 @@ struct Args {
   int N, heads, Lq, Lk, d, tiles, nblk;
   float alpha, drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state;  // nullable: offset += state->rng_base (ABI 600)
 };
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, uint32_t bytes) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NTHR) void scores_kernel(const Args g) {
   const uint32_t tile_bytes = (uint32_t)rows * (uint32_t)g.Lk * 2u;
   uint32_t rkey[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rkey[i] = g.drop_p > 0.f ? rng_row_key(g.seed, g.offset + (uint64_t)(grow0 + 64 * wr + 16 * i + lr)) : 0u;
+  for (int i = 0; i < 4; ++i) rkey[i] = g.drop_p > 0.f ? rng_row_key(g.seed, g.offset + rng_base_of(g.state) + (uint64_t)(grow0 + 64 * wr + 16 * i + lr)) : 0u;
   // per-lane byte offset of (query block i, block pair pr) inside the tile's [rows, Lk] slice; columns beyond Lk -> out of range
   auto mat_off = [&](int i, int pr) -> int {
     const int key0 = 96 * wc + 32 * pr + 8 * gq;
@@ -628,7 +629,7 @@ static void fill_scores(attn_sc::Args& a, const CaseAttnDesc* d) {
   a.N = (int)d->N; a.heads = (int)d->heads; a.Lq = (int)d->Lq; a.Lk = (int)d->Lk; a.d = (int)d->head_dim;
   a.tiles = (int)((d->Lq + 127) / 128);
   a.nblk = a.tiles * a.heads * a.N;
-  a.alpha = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  a.alpha = d->scale; a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset; a.state = d->state;
 }
 
 extern "C" int case_attention_scores_fwd(const CaseAttnDesc* d, const void* q, const void* k, const uint8_t* key_valid, void* p,

@@ -124,6 +124,15 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// ABI 600: the per-step base of the dropout counter stream may live in caller-owned device memory (CaseStepState.rng_base) so that a
+// captured hipGraph draws new masks on every replay.  The pointer is a kernel argument (uniform) and nobody writes the struct while a
+// kernel that reads it runs, so the load goes through the CONSTANT address space: one s_load_dwordx2 into scalar registers, no VGPR.
+__device__ __forceinline__ uint64_t rng_base_of(const CaseStepState* st) {
+  if (st == nullptr) return 0;
+  typedef const __attribute__((address_space(4))) uint64_t* const_u64_ptr;
+  return *(const_u64_ptr)(uintptr_t)st;  // rng_base is the first member
+}
+
 // Counter-based RNG: uniform in [0,1) from (seed, 64-bit element index), keyed by element index so forward and backward
 // (and the fused / unfused attention paths) regenerate the same keep mask.  One 32-bit hash serves TWO consecutive elements
 // (16 bits each, element index >> 1 is hashed): 32-bit integer multiplies are quarter rate on gfx950 and the two rounds of

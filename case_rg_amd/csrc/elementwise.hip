@@ -15,7 +15,8 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
 
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed,
-                               uint64_t offset) {
+                               uint64_t offset, const CaseStepState* state) {
+  offset += rng_base_of(state);
   const float scale = 1.f / (1.f - p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     Elem<T>::st(y + i, rng_uniform(seed, offset + (uint64_t)i) >= p ? Elem<T>::ld(x + i) * scale : 0.f);
@@ -118,7 +119,8 @@ __global__ void add_n_vec_kernel(const AddNArgs a, T* __restrict__ o, int64_t nv
 
 template <typename T>
 __global__ void dropout_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t nvec, float p, uint64_t seed,
-                                   uint64_t offset) {
+                                   uint64_t offset, const CaseStepState* state) {
+  offset += rng_base_of(state);
   constexpr int E = Vec16<T>::N;
   const float scale = 1.f / (1.f - p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
@@ -260,7 +262,9 @@ __global__ void scale_add_rows_kernel(const T* __restrict__ x, const float* __re
 template <typename T>
 __global__ void embed_pos_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                      const float* __restrict__ pe, T* __restrict__ out, int64_t rows, int64_t seq_len,
-                                     int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset) {
+                                     int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset,
+                                     const CaseStepState* state) {
+  offset += rng_base_of(state);
   const int64_t n = rows * H;
   const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -280,7 +284,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_pos_fwd_vec_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                                 const float* __restrict__ pe, T* __restrict__ out, unsigned chunks,
                                                                 unsigned seq_len, unsigned H8, int64_t vocab, float scale, float drop_p,
-                                                                uint64_t seed, uint64_t offset) {
+                                                                uint64_t seed, uint64_t offset, const CaseStepState* state) {
+  offset += rng_base_of(state);
   const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (unsigned ci = blockIdx.x * 256u + threadIdx.x; ci < chunks; ci += gridDim.x * 256u) {
     const unsigned r = ci / H8, c = (ci - r * H8) * 8u;
@@ -309,7 +314,8 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_vec_kernel(const int64_t* _
 template <typename T>
 __global__ void embed_pos_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d_out,
                                      float* __restrict__ d_table, int64_t rows, int64_t H, int64_t vocab, float scale,
-                                     float drop_p, uint64_t seed, uint64_t offset) {
+                                     float drop_p, uint64_t seed, uint64_t offset, const CaseStepState* state) {
+  offset += rng_base_of(state);
   const int64_t n = rows * H;
   const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -604,13 +610,13 @@ extern "C" int case_add_n(const void* const* srcs, int32_t count, void* out, int
   EW_DISPATCH("case_add_n", n / ev, add_n_vec_kernel, a, (T*)out, n / ev);
 }
 
-extern "C" int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,
-                            case_stream_t stream) {
+extern "C" int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const CaseStepState* state,
+                            int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "case_dropout: bad argument");
   const int ev = dtype == CASE_BF16 ? 8 : 4;
   if (n % ev == 0 && al16(x) && al16(y))
-    EW_DISPATCH("case_dropout", n / ev, dropout_vec_kernel, (const T*)x, (T*)y, n / ev, p, seed, offset);
-  EW_DISPATCH("case_dropout", n, dropout_kernel, (const T*)x, (T*)y, n, p, seed, offset);
+    EW_DISPATCH("case_dropout", n / ev, dropout_vec_kernel, (const T*)x, (T*)y, n / ev, p, seed, offset, state);
+  EW_DISPATCH("case_dropout", n, dropout_kernel, (const T*)x, (T*)y, n, p, seed, offset, state);
 }
 
 extern "C" int case_mask_rows(const void* x, const uint8_t* row_valid, void* y, int64_t rows, int64_t cols,
@@ -692,7 +698,7 @@ extern "C" int case_scale_add_rows(const void* x, const float* pe, void* y, int6
 
 extern "C" int case_embed_pos_fwd(const int64_t* ids, const float* table, const float* pe, void* out, int64_t rows,
                                   int64_t seq_len, int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed,
-                                  uint64_t offset, int32_t dtype, case_stream_t stream) {
+                                  uint64_t offset, const CaseStepState* state, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(ids && table && pe && out && rows > 0 && seq_len > 0 && H > 0 && vocab > 0, "case_embed_pos_fwd: bad argument");
   if ((dtype == CASE_BF16 || dtype == CASE_F32) && H % 8 == 0 && al16(table) && al16(pe) && al16(out) && rows * (H / 8) < (1ll << 31) &&
       seq_len < (1ll << 31)) {
@@ -701,22 +707,22 @@ extern "C" int case_embed_pos_fwd(const int64_t* ids, const float* table, const 
     hipStream_t s_ = (hipStream_t)stream;
     if (dtype == CASE_F32)
       hipLaunchKernelGGL(embed_pos_fwd_vec_kernel<float>, grid, dim3(256), 0, s_, ids, table, pe, (float*)out, chunks, (unsigned)seq_len,
-                         (unsigned)(H / 8), vocab, scale, drop_p, seed, offset);
+                         (unsigned)(H / 8), vocab, scale, drop_p, seed, offset, state);
     else
       hipLaunchKernelGGL(embed_pos_fwd_vec_kernel<bf16_t>, grid, dim3(256), 0, s_, ids, table, pe, (bf16_t*)out, chunks, (unsigned)seq_len,
-                         (unsigned)(H / 8), vocab, scale, drop_p, seed, offset);
+                         (unsigned)(H / 8), vocab, scale, drop_p, seed, offset, state);
     return case_check_launch("case_embed_pos_fwd");
   }
   EW_DISPATCH("case_embed_pos_fwd", rows * H, embed_pos_fwd_kernel, ids, table, pe, (T*)out, rows, seq_len, H, vocab, scale,
-              drop_p, seed, offset);
+              drop_p, seed, offset, state);
 }
 
 extern "C" int case_embed_pos_bwd(const int64_t* ids, const void* d_out, float* d_table, int64_t rows, int64_t H,
-                                  int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
-                                  case_stream_t stream) {
+                                  int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset, const CaseStepState* state,
+                                  int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(ids && d_out && d_table && rows > 0 && H > 0 && vocab > 0, "case_embed_pos_bwd: bad argument");
   EW_DISPATCH("case_embed_pos_bwd", rows * H, embed_pos_bwd_kernel, ids, (const T*)d_out, d_table, rows, H, vocab, scale,
-              drop_p, seed, offset);
+              drop_p, seed, offset, state);
 }
 
 extern "C" int case_masked_mean_fwd(const void* x, const uint8_t* valid, void* out, int64_t n, int64_t L, int64_t H,

@@ -34,6 +34,7 @@ struct Args {
   int nwg;
   float alpha, drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state;  // nullable: offset += state->rng_base (ABI 600)
   int vec_a, vec_b;  // 16-byte global loads are legal for the operand
   int vec_c;         // 16-byte accesses are legal for C / aux / aux_out / bias_col
   float* rowsum;     // case_gemm_dw_bias: pre-zeroed f32 [M], receives sum_k op(A)[m, k] (the bias gradient of a weight-gradient GEMM)
@@ -111,7 +112,7 @@ int prepare(const CaseGemmDesc* d, const void* A, const void* B, void* C, const 
   a.ln_gamma = a.ln_beta = nullptr;
   a.ln_out = nullptr;
   a.ln_eps = 0.f;
-  a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset;
+  a.drop_p = d->drop_p; a.seed = d->seed; a.offset = d->offset; a.state = d->state;
   // 16-byte loads need the contiguous extent, every leading stride and the base to be 16-byte multiples
   auto aligned = [&](const void* p, int64_t ld, int64_t s1, int64_t s2, int64_t extent) {
     return ((uintptr_t)p % 16 == 0) && (ld % ept == 0) && (s1 % ept == 0) && (s2 % ept == 0) && (extent % ept == 0);

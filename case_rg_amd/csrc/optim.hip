@@ -60,6 +60,7 @@ struct AdamArgs {
   // derived on the host in double, as torch's _single_tensor_adam does: 1 - beta1, 1 - beta2; the step-dependent lr / (1 - beta1^t)
   // and sqrt(1 - beta2^t) are per tensor (CaseOptTensor.step_size / .bc2_sqrt)
   float max_norm, one_m_b1, beta2, one_m_b2, eps, ema_w;
+  const CaseStepState* state;  // ABI 600, nullable: step_size / bc2_sqrt of the entries with a gradient come from the device struct
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float clip, float step_size,
@@ -89,9 +90,14 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_adam_ema_kernel(const CaseO
       for (int64_t i = begin + threadIdx.x; i < end; i += OPT_THREADS) sh[i] = sh[i] + a.ema_w * (p[i] - sh[i]);
     return;
   }
+  float step_size = t.step_size, bc2_sqrt = t.bc2_sqrt;
+  if (a.state) {  // a captured step: the table is static, the step-dependent scalars are read when the kernel runs
+    step_size = a.state->step_size;
+    bc2_sqrt = a.state->bc2_sqrt;
+  }
   for (int64_t i = begin + threadIdx.x; i < end; i += OPT_THREADS) {
     float pi = p[i], mi = m[i], vi = v[i];
-    adam_one(pi, g[i], mi, vi, a, clip, t.step_size, t.bc2_sqrt);
+    adam_one(pi, g[i], mi, vi, a, clip, step_size, bc2_sqrt);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
@@ -110,12 +116,34 @@ extern "C" int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunk
 }
 
 extern "C" int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
-                                   double beta1, double beta2, double eps, double ema_w, case_stream_t stream) {
+                                   double beta1, double beta2, double eps, double ema_w, const CaseStepState* state, case_stream_t stream) {
   CASE_REQUIRE(table && chunks && nchunks > 0 && nchunks < (1ll << 31), "case_optim_adam_ema: bad argument");
   CASE_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., "case_optim_adam_ema: bad hyper-parameters");
-  const AdamArgs a = {sumsq, max_norm, (float)(1. - beta1), (float)beta2, (float)(1. - beta2), (float)eps, (float)ema_w};
+  const AdamArgs a = {sumsq, max_norm, (float)(1. - beta1), (float)beta2, (float)(1. - beta2), (float)eps, (float)ema_w, state};
   hipLaunchKernelGGL(optim_adam_ema_kernel, dim3((unsigned)nchunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, table, chunks, a);
   return case_check_launch("case_optim_adam_ema");
 }
 
 extern "C" int case_optim_chunk_elems(void) { return OPT_CHUNK; }
+
+// ---- ABI 600: the device-resident step state ------------------------------------------------------------------------------------
+namespace {
+__global__ void step_advance_kernel(CaseStepState* st, uint64_t rng_stride, double beta1, double beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int32_t step = st->step + 1;
+  st->step = step;
+  st->rng_base += rng_stride;
+  // lr / (1 - beta1^step) and sqrt(1 - beta2^step) in double, rounded once: the host forms the table entries the same way (optim.py)
+  st->step_size = (float)((double)st->lr / (1.0 - pow(beta1, (double)step)));
+  st->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+}
+}  // namespace
+
+extern "C" int case_sizeof_step_state(void) { return (int)sizeof(CaseStepState); }
+
+extern "C" int case_step_advance(CaseStepState* state, uint64_t rng_stride, double beta1, double beta2, case_stream_t stream) {
+  CASE_REQUIRE(state != nullptr && (rng_stride & 1) == 0, "case_step_advance: null state or odd RNG stride (the kernels hash element pairs)");
+  CASE_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., "case_step_advance: bad hyper-parameters");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, rng_stride, beta1, beta2);
+  return case_check_launch("case_step_advance");
+}

@@ -279,6 +279,7 @@ struct LnDrop {
   void* out;
   float p;
   uint64_t seed, offset;
+  const CaseStepState* state;  // nullable: offset += state->rng_base (ABI 600)
 };
 template <typename T, typename V = Vec16<T>>
 __device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, const float (&o)[V::N]) {
@@ -299,7 +300,7 @@ __device__ __forceinline__ void ln_store_dropped(const LnDrop& dr, int64_t idx, 
 #pragma unroll
   for (int e = 0; e < E; e += 2) {  // idx is a multiple of E: even
     float u0, u1;
-    rng_uniform2(dr.seed, dr.offset + (uint64_t)(idx + e), u0, u1);
+    rng_uniform2(dr.seed, dr.offset + rng_base_of(dr.state) + (uint64_t)(idx + e), u0, u1);
     q[e] = u0 >= dr.p ? q[e] * scale : 0.f;
     q[e + 1] = u1 >= dr.p ? q[e + 1] * scale : 0.f;
   }
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const CaseSoftmaxDesc 
     s = row_sum<TPR>(s, red);
     if (!live) continue;
     const float inv = s > 0.f ? 1.f / s : 0.f;
-    const uint32_t rkey = d.drop_p > 0.f ? rng_row_key(d.seed, d.offset + (uint64_t)rr) : 0u;
+    const uint32_t rkey = d.drop_p > 0.f ? rng_row_key(d.seed, d.offset + rng_base_of(d.state) + (uint64_t)rr) : 0u;
     for (int64_t c = t; c < d.C; c += TPR) {
       float p = 0.f;
       if (row_ok && c < cmax && (!cv || cv[c]) && inv > 0.f) p = expf(Elem<TI>::ld(xr + c) - m) * inv;
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const CaseSoftmaxDesc 
     const int64_t row = base + sub;
     const bool live = row < total;
     const int64_t rr = live ? row : 0;
-    const uint32_t rkey = d.drop_p > 0.f ? rng_row_key(d.seed, d.offset + (uint64_t)rr) : 0u;
+    const uint32_t rkey = d.drop_p > 0.f ? rng_row_key(d.seed, d.offset + rng_base_of(d.state) + (uint64_t)rr) : 0u;
     float dot = 0.f;
     if (live)
       for (int64_t c = t; c < d.C; c += TPR) {
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const CaseSoftmaxD
       for (int e = 0; e < 8; ++e) v[j][e] *= inv;
       Vec16<bf16_t>::store(p_out + row * d.C + c0, v[j]);
       if (d.drop_p > 0.f) {
-        attn_dropout8(v[j], rng_row_key(d.seed, d.offset + (uint64_t)row), (uint32_t)c0, rng_threshold(d.drop_p), keep_scale);
+        attn_dropout8(v[j], rng_row_key(d.seed, d.offset + rng_base_of(d.state) + (uint64_t)row), (uint32_t)c0, rng_threshold(d.drop_p), keep_scale);
         Vec16<bf16_t>::store(y_out + row * d.C + c0, v[j]);
       }
     }
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const CaseSoftmaxD
       if (c0 < d.C) {
         Vec16<bf16_t>::load(dy + row * d.C + c0, g[j]);
         Vec16<bf16_t>::load(p + row * d.C + c0, pv[j]);
-        if (d.drop_p > 0.f) attn_dropout8(g[j], rng_row_key(d.seed, d.offset + (uint64_t)row), (uint32_t)c0, rng_threshold(d.drop_p), keep_scale);
+        if (d.drop_p > 0.f) attn_dropout8(g[j], rng_row_key(d.seed, d.offset + rng_base_of(d.state) + (uint64_t)row), (uint32_t)c0, rng_threshold(d.drop_p), keep_scale);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dot += g[j][e] * pv[j][e];
       }
@@ -1136,12 +1137,12 @@ extern "C" int case_layernorm_bwd_concat5(const void* dy, const void* x, const f
 
 extern "C" int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                                           void* dx_dropped, float* d_gamma, float* d_beta, int64_t rows, int64_t cols, float p, uint64_t seed,
-                                          uint64_t offset, int32_t dtype, case_stream_t stream) {
+                                          uint64_t offset, const CaseStepState* state, int32_t dtype, case_stream_t stream) {
   CASE_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_dropped && d_gamma && d_beta && rows > 0 && cols > 0 && p > 0.f && p < 1.f,
                "case_layernorm_bwd_dropout: bad argument");
   // the dual-output kernels draw one 64-bit hash per element PAIR (offset + even index); case_dropout does the same only for even offsets
   CASE_REQUIRE((offset & 1) == 0, "case_layernorm_bwd_dropout: the RNG offset must be even (the mask is drawn per element pair)");
-  const LnDrop dr = {dx_dropped, p, seed, offset};
+  const LnDrop dr = {dx_dropped, p, seed, offset, state};
   hipStream_t s = (hipStream_t)stream;
   bool ok = false;
   if (dtype == CASE_F32 && ln_vec_ok<float>(dy, x, dx, cols) && ln_vec_ok<float>(dx_dropped, nullptr, nullptr, cols))

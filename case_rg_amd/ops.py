@@ -45,6 +45,14 @@ def _ptr(t, offset_elems=0):
     return t.data_ptr() + offset_elems * t.element_size()
 
 
+def _drop4(drop):
+    """A dropout site as the descriptors take it: (p, seed, offset, state) -- ``state`` is None or the address of the CaseStepState whose
+    rng_base the kernels add to ``offset`` (config.next_rng); None / a 3-tuple = arguments only."""
+    if drop is None:
+        return 0.0, 0, 0, None
+    return tuple(drop) if len(drop) == 4 else tuple(drop) + (None,)
+
+
 def _u8(mask):
     """bool mask -> uint8 view (same storage) or None."""
     if mask is None:
@@ -221,7 +229,7 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor
             raise TypeError("gemm %s must be float32, got %s" % (name, t.dtype))
     if drop is not None and drop[0] > 0.0:
         epilogue |= A.EPI_DROPOUT
-        d.drop_p, d.seed, d.offset = drop
+        d.drop_p, d.seed, d.offset, d.state = _drop4(drop)
     d.epilogue, d.split_k, d.alpha = epilogue, split_k, alpha
     if TILE_TRACE is not None:
         TILE_TRACE.append(A.lib.case_gemm_tile_for(d, _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off), _ptr(bias_col), _ptr(aux),
@@ -370,9 +378,9 @@ def _colsum(g2, out=None):
     return out
 
 
-def _dropout_raw(x, p, seed, offset):
+def _dropout_raw(x, p, seed, offset, state=None):
     y = torch.empty_like(x)
-    A.call("case_dropout", _ptr(x), _ptr(y), x.numel(), p, seed, offset, _code(x), _stream())
+    A.call("case_dropout", _ptr(x), _ptr(y), x.numel(), p, seed, offset, state, _code(x), _stream())
     return y
 
 
@@ -426,7 +434,7 @@ def _ln_tail_backward(dn, y2, g, mean, rstd, drop):
     if drop is not None and C % chunk == 0 and C // chunk <= 8:
         gm = torch.empty_like(y2)
         A.call("case_layernorm_bwd_dropout", _ptr(dn2), _ptr(y2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(gm), _ptr(dg), _ptr(db), R, C,
-               drop[0], drop[1], drop[2], _code(y2), _stream())
+               drop[0], drop[1], drop[2], drop[3], _code(y2), _stream())
         return dy, gm, dg, db
     A.call("case_layernorm_bwd", _ptr(dn2), _ptr(y2), None, _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), None, _ptr(dg), _ptr(db), R, C,
            _code(y2), _stream())
@@ -453,8 +461,7 @@ class LinearFn(Function):
         if b is not None:
             epi |= A.EPI_BIAS_COL
         if p_drop > 0.0:
-            seed, off = config.next_rng(M * N)
-            drop = (p_drop, seed, off)
+            drop = (p_drop,) + config.next_rng(M * N)
         if residual is not None:
             res2 = residual.reshape(M, N).contiguous()
             epi |= A.EPI_RESIDUAL
@@ -765,7 +772,7 @@ def _softmax_desc(outer, inner, R, C, causal, in_dt, out_dt, drop):
     d = A.SoftmaxDesc()
     d.outer, d.inner, d.R, d.C = outer, inner, R, C
     d.causal, d.in_dtype, d.out_dtype = int(causal), in_dt, out_dt
-    d.drop_p, d.seed, d.offset = drop if drop is not None else (0.0, 0, 0)
+    d.drop_p, d.seed, d.offset, d.state = _drop4(drop)
     return d
 
 
@@ -864,7 +871,7 @@ def _attn_desc(N, heads, Lq, Lk, d, q_src, k_src, v_src, causal, alpha, drop):
     ad.sq, ad.sk, ad.sv = Lq * q_src.shape[2], Lk * k_src.shape[2], Lk * v_src.shape[2]
     ad.ldo, ad.so = heads * d, Lq * heads * d
     ad.causal, ad.scale = int(causal), alpha
-    ad.drop_p, ad.seed, ad.offset = drop if drop is not None else (0.0, 0, 0)
+    ad.drop_p, ad.seed, ad.offset, ad.state = _drop4(drop)
     return ad
 
 
@@ -1077,6 +1084,7 @@ DECODE_ABSORB_MIN_KEYS = 1024
 def decode_absorb_supported(memory, embed_dim, heads):
     return (DECODE_ABSORB != "off" and torch.is_tensor(memory) and memory.is_cuda and memory.dtype == torch.bfloat16 and memory.dim() == 3
             and embed_dim == 512 and heads == 8 and memory.shape[2] == 512 and memory.shape[1] >= DECODE_ABSORB_MIN_KEYS
+            and not torch.is_grad_enabled()  # raw-pointer launches without an autograd Function: inference under no_grad only
             and bool(A.lib.case_abi_features() & A.FEAT_ATTN_DECODE_MQA))
 
 
@@ -1237,10 +1245,10 @@ class EmbedPosFn(Function):
         rows, (V, H) = ids.numel(), table.shape
         ids_c = ids.contiguous()
         out = torch.empty(*ids.shape, H, dtype=dtype, device=table.device)
-        drop = (p_drop,) + config.next_rng(rows * H) if p_drop > 0.0 else (0.0, 0, 0)
+        drop = (p_drop,) + config.next_rng(rows * H) if p_drop > 0.0 else (0.0, 0, 0, None)
         scale = math.sqrt(H)
         A.call("case_embed_pos_fwd", _ptr(ids_c), _ptr(table.detach()), _ptr(pe), _ptr(out), rows, seq_len, H, V, scale, drop[0],
-               drop[1], drop[2], _DT[dtype], _stream())
+               drop[1], drop[2], drop[3], _DT[dtype], _stream())
         ctx.save_for_backward(ids_c)
         ctx.meta = (V, H, scale, drop)
         return out
@@ -1252,7 +1260,7 @@ class EmbedPosFn(Function):
         d_out = d_out if d_out.is_contiguous() else d_out.contiguous()
         d_table = _zeros_like_shapes(d_out.device, (V, H))[0]
         A.call("case_embed_pos_bwd", _ptr(ids_c), _ptr(d_out), _ptr(d_table), ids_c.numel(), H, V, scale, drop[0], drop[1],
-               drop[2], _code(d_out), _stream())
+               drop[2], drop[3], _code(d_out), _stream())
         return None, d_table, None, None, None, None
 
 
@@ -1684,6 +1692,7 @@ POINTER_FUSED_MIN_BATCH = 96
 def pointer_decode_supported(memory):
     return (POINTER_FUSED != "off" and torch.is_tensor(memory) and memory.is_cuda and memory.dtype == torch.bfloat16 and memory.dim() == 3
             and memory.shape[2] == 512 and memory.shape[1] <= 28000 and memory.shape[0] >= POINTER_FUSED_MIN_BATCH
+            and not torch.is_grad_enabled()  # (no autograd Function behind K22)
             and bool(A.lib.case_abi_features() & A.FEAT_POINTER_DECODE))
 
 
@@ -1719,6 +1728,7 @@ POINTER_HEAD = os.environ.get("CASE_POINTER_HEAD", "auto")
 
 def pointer_head_supported(source_map, V, nmem):
     return (POINTER_HEAD != "off" and isinstance(source_map, SortedSource) and V <= 36000 and 1 <= nmem <= 4
+            and not torch.is_grad_enabled()  # (no autograd Function behind K23)
             and bool(A.lib.case_abi_features() & A.FEAT_POINTER_HEAD))
 
 

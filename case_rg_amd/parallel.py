@@ -15,6 +15,8 @@ import torch.distributed as dist
 
 
 class GradSync:
+    ABORT_WAIT = __import__("datetime").timedelta(seconds=30)  # abort(): longest wait per collective already in flight
+
     def __init__(self, model, bucket_mb=64, process_group=None, force=False, reserve_cus=None, comm_dtype=None):
         """``force`` keeps the bucket / hook / collective machinery active on a one-rank group (used by the GPU test that
         drives the RCCL path on a single device).
@@ -84,12 +86,20 @@ class GradSync:
         flight -- every rank launched the same ones --, forget the partial state and hand the reserved CUs back."""
         if not self.active:
             return
-        for b in self.buckets:
-            if b["work"] is not None:
-                b["work"].wait()
-            b["work"], b["pending"] = None, len(b["items"])
-        self._next = 0
-        self._reserve(False)
+        try:
+            for b in self.buckets:
+                if b["work"] is not None:
+                    # bounded: if a peer died, its half of the collective never arrives (the RCCL watchdog ends the job at the group's
+                    # own timeout); an abandoned step must not hang here for that long
+                    try:
+                        b["work"].wait(timeout=self.ABORT_WAIT)
+                    except TypeError:  # a backend whose Work.wait takes no timeout
+                        b["work"].wait()
+        finally:
+            for b in self.buckets:
+                b["work"], b["pending"] = None, len(b["items"])
+            self._next = 0
+            self._reserve(False)
 
     def _on_grad(self, p):
         if not self._armed:
@@ -168,6 +178,22 @@ class GradSync:
             b["work"], b["pending"] = None, len(b["items"])
         self._next = 0
         self._reserve(False)
+
+    def reduce_now(self):
+        """All-reduce the gradients as they stand in ``param.grad`` WITHOUT having seen backward (a replayed hipGraph fires no hooks):
+        every bucket is gathered and launched in order, then ``finish()``'s wait / average / view assignment.  ``None`` gradients count
+        as zeros, as in ``finish()``."""
+        if not self.active:
+            return
+        self._armed = True
+        self.finish()
+
+    def adopt_bucket_views(self):
+        """``param.grad`` := the parameter's view of its flat bucket, for every parameter, without communication -- the state
+        ``finish()`` leaves behind.  The optimizer segment of a captured step is recorded against these persistent addresses."""
+        for b in self.buckets:
+            for (p, _, _), view in zip(b["items"], b["views"]):
+                p.grad = view
 
     def exposed_ms(self, last=None):
         """Mean time per step the compute stream waited in finish() (synchronises on the recorded events)."""

@@ -44,8 +44,12 @@ enum {
  * written against (case_rg_amd/_abi.py refuses any other library).  Bumped with every struct or signature change:
  *   100 round 1 | 200 round 2 (case_gemm_dw_bias, decode, optimizer) | 300 round 3 (CaseOptTensor 56 -> 64 bytes, K16 / K17)
  *   400 round 4 (K18 / K19 resident attention, case_attention_bwd scratch = 2 N heads Lq floats, workspace query, reserved CUs)
- *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode, K23 case_pointer_head_decode, case_gemm_ln). */
-#define CASE_ABI_VERSION 500
+ *   500 round 5 (K21 case_attention_decode_mqa, K22 case_pointer_attend_decode, K23 case_pointer_head_decode, case_gemm_ln)
+ *   600 round 6 (CaseStepState: the per-step scalars -- dropout counter base, Adam step size / bias correction -- may live in caller-owned
+ *       DEVICE memory instead of riding in the arguments, so that a hipGraph-captured training step draws new masks and takes the right
+ *       Adam step on every replay; `state` members / arguments on every dropout site and on case_optim_adam_ema; case_step_advance;
+ *       K8 case_interaction_fwd). */
+#define CASE_ABI_VERSION 600
 int case_version(void);
 /* what the build contains, as a bit mask */
 enum {
@@ -66,6 +70,34 @@ enum {
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident step state (round 6).  A training step of common/CumulativeTrainer.py:52-78 has three kinds of scalars that change
+ * from step to step: the position of the dropout counter stream (every nn.Dropout / F.dropout site: common/TransformerEncoder.py:68,72,75
+ * ...), the learning rate the scheduler set (CaSE/Run.py:28) and Adam's bias corrections (torch.optim.Adam, CaSE/Run.py:27).  As kernel
+ * ARGUMENTS they are frozen into a captured hipGraph -- a replayed step would redraw the same masks.  Every entry point that takes
+ * (seed, offset) or the Adam scalars therefore also takes a nullable `const CaseStepState* state`, a DEVICE pointer to 64 caller-owned
+ * bytes that the kernels read when they run:
+ *   - dropout sites hash (seed, offset + state->rng_base + element index): the caller numbers the sites of ONE step from offset 0 and
+ *     moves rng_base by the step's consumption between steps (rng_base must stay even: the kernels hash element pairs);
+ *   - case_optim_adam_ema takes step_size / bc2_sqrt from the state instead of the table entries.
+ * state == NULL is the round-5 behaviour (arguments only).  The caller writes the struct -- a 64-byte hipMemcpyAsync from pinned memory
+ * ahead of the step (exact for any scheduler), or case_step_advance on the stream (no host involvement per step).  The library only
+ * reads it; like every pointer here it is never retained.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t rng_base; /* added to the `offset` of every dropout site that is given this state; even */
+  float step_size;   /* lr / (1 - beta1^step)   -- as CaseOptTensor.step_size */
+  float bc2_sqrt;    /* sqrt(1 - beta2^step)    -- as CaseOptTensor.bc2_sqrt */
+  float lr;          /* the learning rate step_size was formed from (read by case_step_advance only) */
+  int32_t step;      /* optimizer steps taken, INCLUDING the one these scalars belong to */
+  uint64_t reserved[5];
+} CaseStepState;     /* 64 bytes */
+int case_sizeof_step_state(void);
+/* One single-thread launch that moves the state to the next step: step += 1, rng_base += rng_stride (even), and, with the state's lr,
+ * step_size = lr / (1 - beta1^step), bc2_sqrt = sqrt(1 - beta2^step), formed in double and rounded to f32 once (what
+ * case_rg_amd/optim.py does on the host).  For replay loops that never return to the host; a scheduler that changes lr writes state->lr. */
+int case_step_advance(CaseStepState* state, uint64_t rng_stride, double beta1, double beta2, case_stream_t stream);
 
 /* Compute units the persistent kernels (256 x 256 GEMM, K16 .. K19) leave free -- the ONE piece of mutable library configuration:
  * with world_size > 1 RCCL's kernels must be resident beside them for the gradient all-reduce to overlap backward
@@ -124,6 +156,7 @@ typedef struct {
   float alpha;
   float drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state; /* nullable: offset += state->rng_base on the device (ABI 600) */
 } CaseGemmDesc;
 
 int case_gemm(const CaseGemmDesc* d, const void* A, const void* B, void* C, const float* bias_col,
@@ -169,10 +202,10 @@ int case_gemm_tile_for(const CaseGemmDesc* d, const void* A, const void* B, cons
  * ------------------------------------------------------------------------------------------- */
 int case_embed_pos_fwd(const int64_t* ids, const float* table, const float* pe, void* out, int64_t rows,
                        int64_t seq_len, int64_t H, int64_t vocab, float scale, float drop_p, uint64_t seed,
-                       uint64_t offset, int32_t dtype, case_stream_t stream);
+                       uint64_t offset, const CaseStepState* state, int32_t dtype, case_stream_t stream);
 int case_embed_pos_bwd(const int64_t* ids, const void* d_out, float* d_table, int64_t rows, int64_t H,
-                       int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
-                       case_stream_t stream);
+                       int64_t vocab, float scale, float drop_p, uint64_t seed, uint64_t offset, const CaseStepState* state,
+                       int32_t dtype, case_stream_t stream);
 
 /* stand-alone PositionalEmbedding.forward (common/PositionalEmbedding.py:44-48): y = x*scale + pe[row % seq_len]
  * (pe may be null: plain scaling, used as its backward) */
@@ -201,7 +234,7 @@ int case_layernorm_bwd(const void* dy, const void* x, const void* x2, const floa
  * `offset` must be EVEN (the mask is drawn per element pair; CASE_E_ARG otherwise -- case_dropout itself accepts odd offsets). */
 int case_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                                void* dx_dropped, float* d_gamma, float* d_beta, int64_t rows, int64_t cols, float p, uint64_t seed,
-                               uint64_t offset, int32_t dtype, case_stream_t stream);
+                               uint64_t offset, const CaseStepState* state, int32_t dtype, case_stream_t stream);
 /* The backward of LN(G), G = concat5(E, A1, A2) = [E | A1 | A2 | E o A1 | E o A2] with padded rows zeroed (common/Interaction.py:65-72 feeding
  * common/TransformerBlock.py:25), fused with the backward of the concatenation: dE, dA1, dA2 [rows, H] come out directly, dG (5H wide)
  * is never written.  x = G as the forward wrote it; dx_add (nullable, [rows, 5H]) a second gradient of G (its residual use, block :27).
@@ -226,6 +259,7 @@ typedef struct {
   int32_t in_dtype, out_dtype;
   float drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state; /* nullable: offset += state->rng_base on the device (ABI 600) */
 } CaseSoftmaxDesc;
 
 int case_softmax_fwd(const CaseSoftmaxDesc* d, const void* x, const uint8_t* col_valid, const uint8_t* row_valid,
@@ -257,6 +291,7 @@ typedef struct {
   int32_t causal;
   float scale, drop_p;
   uint64_t seed, offset;
+  const CaseStepState* state; /* nullable: offset += state->rng_base on the device (ABI 600) */
 } CaseAttnDesc;
 
 int case_attention_supported(int64_t head_dim);
@@ -334,8 +369,8 @@ int case_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, 
  * tensors of common/Interaction.py:32-63, each read by 2-5 products).  n a multiple of 16 bytes' worth of elements, 16-byte aligned. */
 int case_add_n(const void* const* srcs, int32_t count, void* out, int64_t n, int32_t dtype, case_stream_t stream);
 /* dropout with a counter RNG keyed by (seed, offset + element index); same call regenerates the mask in bwd */
-int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int32_t dtype,
-                 case_stream_t stream);
+int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const CaseStepState* state,
+                 int32_t dtype, case_stream_t stream);
 /* zero rows whose valid flag is 0: TransformerBlock.py:31, Interaction.py:68-70 */
 int case_mask_rows(const void* x, const uint8_t* row_valid, void* y, int64_t rows, int64_t cols, int32_t dtype,
                    case_stream_t stream);
@@ -480,8 +515,10 @@ int case_optim_chunk_elems(void);
 int case_sizeof_opt_tensor(void); /* sizeof(CaseOptTensor) as the library was built: a binder checks its own layout against it */
 int case_optim_sumsq(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, float* partials, float* sumsq,
                      case_stream_t stream);
+/* state (nullable, ABI 600): step_size / bc2_sqrt of EVERY entry with a gradient are read from the device struct instead of the table
+ * (all such parameters then share one step count -- a captured step keeps its table static). */
 int case_optim_adam_ema(const CaseOptTensor* table, const int32_t* chunks, int64_t nchunks, const float* sumsq, float max_norm,
-                        double beta1, double beta2, double eps, double ema_w, case_stream_t stream);
+                        double beta1, double beta2, double eps, double ema_w, const CaseStepState* state, case_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K16  the row-local half of an encoder layer in ONE launch (inference form, bf16, d_model = dim_feedforward = 512):

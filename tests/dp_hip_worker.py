@@ -1,7 +1,7 @@
 """One rank of tests/test_dp_hip_gpu.py: a FRESH process (its own HIP context on device 0) that trains the HIP CaSE model for three
 steps through CumulativeTrainer + FusedAdam + GradSync over a gloo group (RCCL refuses two ranks on one device; the bucket protocol,
 the bucket-view gradients the fused optimizer reads, and the parameter cache are the real ones).
-usage: python tests/dp_hip_worker.py RANK WORLD PORT OUT_DIR"""
+usage: python tests/dp_hip_worker.py RANK WORLD PORT OUT_DIR [graph]   (graph: hipGraph-captured steps, two segments around the all-reduce)"""
 import os
 import sys
 
@@ -37,7 +37,9 @@ def main():
         from case_rg_amd.common.CumulativeTrainer import CumulativeTrainer
         from case_rg_amd.optim import FusedAdam
         model = build(40 + rank)  # ranks start DIFFERENT: the broadcast at GradSync construction must make them rank 0's
-        trainer = CumulativeTrainer(model, None, None, 0, world)
+        graph = len(sys.argv) > 5 and sys.argv[5] == "graph"
+        nsteps = 6 if graph else 3
+        trainer = CumulativeTrainer(model, None, None, 0, world, capture=graph)
         assert trainer.sync is not None and trainer.sync.active and len(trainer.sync.buckets) >= 1
         opt = FusedAdam(model.parameters(), lr=1e-3)
         losses = []
@@ -49,14 +51,14 @@ def main():
             seen.append(_abi.lib.case_get_reserved_cus())
 
         trainer.sync._launch = watched
-        for step in range(3):
+        for step in range(nsteps):
             b = {k: v.cuda() for k, v in shard(step, rank).items()}
             losses.append(trainer.train_batch(0, b, "train", opt))
         torch.cuda.synchronize()
         torch.save({"params": {n: p.detach().cpu() for n, p in model.named_parameters()}, "losses": losses,
                     "buckets": len(trainer.sync.buckets), "exposed_ms": trainer.sync.exposed_ms(),
                     "reserved_cus": trainer.sync.reserved_cus, "reserved_during_backward": seen,
-                    "reserved_after_step": _abi.lib.case_get_reserved_cus(),
+                    "reserved_after_step": _abi.lib.case_get_reserved_cus(), "replays": 0 if trainer.graphs is None else trainer.graphs.replays,
                     "ema": {n: t.detach().cpu() for n, t in trainer.ema.shadow.items()}}, os.path.join(out, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()

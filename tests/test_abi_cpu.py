@@ -31,7 +31,7 @@ def test_ctypes_table_matches_header():
     from case_rg_amd import _abi
     other = {"case_version", "case_last_error", "case_gemm_tile_for", "case_optim_chunk_elems", "case_abi_features", "case_get_reserved_cus",
              "case_sizeof_opt_tensor", "case_workspace_bytes", "case_attention_bwd_scratch_floats", "case_encoder_chain_packed_bytes",
-             "case_gemm_dw_slab_bytes", "case_attention_decode_mqa_workspace", "case_attention_decode_mqa_splits"}
+             "case_gemm_dw_slab_bytes", "case_attention_decode_mqa_workspace", "case_attention_decode_mqa_splits", "case_sizeof_step_state"}
     assert set(_abi.SIGNATURES) | other == _declared()
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for name, args in _abi.SIGNATURES.items():
@@ -42,13 +42,14 @@ def test_ctypes_table_matches_header():
 def test_struct_layouts_match_header_field_order():
     from case_rg_amd import _abi
     text = open(HEADER).read()
-    for cname, struct in (("CaseGemmDesc", _abi.GemmDesc), ("CaseSoftmaxDesc", _abi.SoftmaxDesc)):
+    for cname, struct in (("CaseGemmDesc", _abi.GemmDesc), ("CaseSoftmaxDesc", _abi.SoftmaxDesc), ("CaseAttnDesc", _abi.AttnDesc)):
         body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} %s;" % cname, text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
         for decl in body.split(";"):
             decl = decl.strip()
             if decl:
+                decl = re.sub(r"^const\s+", "", decl).replace("*", " ")  # `const CaseStepState* state` -> type, name
                 fields += [f.strip() for f in decl.split(None, 1)[1].split(",")]
         assert fields == [f[0] for f in struct._fields_], cname
 
@@ -70,6 +71,8 @@ def test_abi_generation_features_and_workspace_queries():
                 _abi.FEAT_ATTN_RESIDENT, _abi.FEAT_RESERVED_CUS):
         assert feats & bit
     assert _abi.lib.case_sizeof_opt_tensor() == C.sizeof(optim._Entry) == 64
+    assert _abi.lib.case_sizeof_step_state() == C.sizeof(_abi.StepState) == 64  # ABI 600: the device-resident step state
+    assert _abi.StepState.rng_base.offset == 0 and _abi.StepState.step_size.offset == 8 and _abi.StepState.bc2_sqrt.offset == 12
     d = _abi.AttnDesc()
     d.N, d.heads, d.Lq, d.Lk, d.head_dim = 3, 8, 40, 4096, 64
     need = _abi.i64(0)

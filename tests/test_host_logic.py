@@ -90,9 +90,17 @@ def test_schedule_definition():
 
 def test_dropout_counter_bookkeeping():
     config.manual_seed(5)
-    s0, o0 = config.next_rng(100)
-    s1, o1 = config.next_rng(7)
-    assert (s0, o0, s1, o1) == (5, 0, 5, 100)
+    s0, o0, st0 = config.next_rng(100)
+    s1, o1, st1 = config.next_rng(7)
+    assert (s0, o0, s1, o1) == (5, 0, 5, 100) and st0 is None and st1 is None  # no device state: arguments only
+    config.set_device_state(0x7f0000001000)
+    # with a device-resident state the sites of a step are numbered from 0; the stream position moves into the base the kernels add
+    assert config.next_rng(3) == (5, 0, 0x7f0000001000) and config.rng_state() == (5, 112)  # offsets stay even
+    assert config.begin_step() == 112 and config.next_rng(10)[1] == 0
+    config.skip_rng(6)  # a replayed capture consumed 6 counters
+    assert config.rng_state() == (5, 128)
+    config.set_device_state(None)
+    assert config.next_rng(2) == (5, 128, None)
     config.set_dropout(False)
     assert config.drop_p(0.1, True) == 0.0
     config.set_dropout(True)

@@ -841,16 +841,16 @@ def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_
     A.call("case_layernorm_bwd", dy.data_ptr(), x.data_ptr(), None, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx0.data_ptr(), None,
            dg0.data_ptr(), db0.data_ptr(), rows, cols, code, 0)
     g0 = torch.empty_like(x)
-    A.call("case_dropout", dx0.data_ptr(), g0.data_ptr(), x.numel(), p, seed, off, code, 0)
+    A.call("case_dropout", dx0.data_ptr(), g0.data_ptr(), x.numel(), p, seed, off, None, code, 0)
     dx1, g1, dg1, db1 = torch.empty_like(x), torch.empty_like(x), torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
     A.call("case_layernorm_bwd_dropout", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx1.data_ptr(),
-           g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols, p, seed, off, code, 0)
+           g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols, p, seed, off, None, code, 0)
     torch.cuda.synchronize()
     if cols_k == 5 and dt == torch.bfloat16:
         # the 5H rows take the one-wave-per-row kernel: its row sums are formed in another order than the row-split kernel's, so dx may
         # differ in the last bf16 bit; the masked copy must still be case_dropout of ITS dx, bit for bit
         _close(dx1, dx0, 8e-3, "dx (one wave per row)")
-        A.call("case_dropout", dx1.data_ptr(), g0.data_ptr(), x.numel(), p, seed, off, code, 0)
+        A.call("case_dropout", dx1.data_ptr(), g0.data_ptr(), x.numel(), p, seed, off, None, code, 0)
         torch.cuda.synchronize()
     else:
         assert torch.equal(dx0, dx1), "dx differs"
@@ -860,7 +860,7 @@ def test_layernorm_backward_with_the_dropout_masked_copy_matches_two_passes_bit_
     _close(db1, db0, 1e-5, "d_beta")
     with pytest.raises(RuntimeError, match="64-lane"):
         A.call("case_layernorm_bwd_dropout", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx1.data_ptr(),
-               g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols - 8, p, seed, off, code, 0)
+               g1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), rows, cols - 8, p, seed, off, None, code, 0)
 
 
 @pytest.mark.parametrize("form", ["self", "cross", "key_is_not_value"])

@@ -43,9 +43,9 @@ for name, addp in (("with dx_add", add.data_ptr()), ("without", None)):
 g2 = torch.empty_like(x)
 def dual():
     A.call("case_layernorm_bwd_dropout", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), g2.data_ptr(),
-           dg.data_ptr(), db.data_ptr(), rows, C, 0.1, 1234, 0, A.BF16, 0)
+           dg.data_ptr(), db.data_ptr(), rows, C, 0.1, 1234, 0, None, A.BF16, 0)
 def plain_then_drop():
     A.call("case_layernorm_bwd", dy.data_ptr(), x.data_ptr(), None, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), None, dg.data_ptr(), db.data_ptr(), rows, C, A.BF16, 0)
-    A.call("case_dropout", dx.data_ptr(), g2.data_ptr(), x.numel(), 0.1, 1234, 0, A.BF16, 0)
+    A.call("case_dropout", dx.data_ptr(), g2.data_ptr(), x.numel(), 0.1, 1234, 0, None, A.BF16, 0)
 t1, t2 = timeit(dual), timeit(plain_then_drop)
 print("5H dual-output LayerNorm backward %.3f ms (%.2f TB/s on 2.52 GB); LayerNorm backward + dropout pass %.3f ms" % (t1, 2.52 / t1, t2), flush=True)
