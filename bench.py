@@ -73,7 +73,9 @@ def parse():
                     help="data parallel: compute units the persistent kernels leave to RCCL while collectives are in flight (default: "
                          "CASE_DP_RESERVE_CUS or 8); sweep 0 / 8 / 16 and compare data_parallel.allreduce_exposed_ms")
     ap.add_argument("--decode-len", type=int, default=64)
-    ap.add_argument("--graph", action="store_true", help="decode: replay the whole greedy pass from one captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="decode: replay the whole greedy pass from one captured hipGraph; train modes: replay the "
+                                                         "training step from a hipGraph recorded after three untimed eager steps (CumulativeTrainer(capture=True): "
+                                                         "dropout base / LR / Adam scalars in device memory, new masks on every replay)")
     return ap.parse_args()
 
 
@@ -128,7 +130,7 @@ def build(a, device):
         from case_rg_amd.Masque.Model import Masque
         model = Masque(a.answer_len, i2v, v2i, a.hidden, enc_layers=a.enc_layers)
     init_params(model)
-    trainer = CumulativeTrainer(model, None, None, device.index, a.gpus)
+    trainer = CumulativeTrainer(model, None, None, device.index, a.gpus, capture=bool(getattr(a, "graph", False)) or None)
     from case_rg_amd.optim import FusedAdam
     # CaSE/Run.py:27 optim.Adam(lr=2.5e-4): same update rule; the trainer's clip / EMA and the bf16 operand refresh ride in its pass (K15)
     opt = FusedAdam(model.parameters(), lr=2.5e-4, low_precision=torch.bfloat16 if a.dtype == "bf16" else None)
@@ -191,11 +193,13 @@ def roofline_step(a, trainer, opt, sched, batch):
         return out
 
     ops.gemm, ops.TILE_TRACE = timed_gemm, []
+    graphs, trainer.graphs = trainer.graphs, None  # the instrumented step is an eager one (a replayed graph calls no Python)
     try:
         trainer.train_batch(0, dict(batch), "train", opt, sched)
         torch.cuda.synchronize()
     finally:
         ops.gemm, ops.TILE_TRACE = raw, None
+        trainer.graphs = graphs
     fam = {}
     shapes = {}
     for key, flops, e0, e1, shape, nbytes in records:
@@ -608,6 +612,10 @@ def main():
     def step():
         return trainer.train_batch(0, dict(batch), "train", opt, sched)
 
+    if trainer.graphs is not None:  # captured steps: two eager steps + the recording pass happen before the contract's warm-up
+        for _ in range(3):
+            step()
+        assert trainer.graphs.replays >= 1, "the training step was not captured"
     for _ in range(a.warmup):
         step()
 
@@ -641,6 +649,7 @@ def main():
                                "query %d, answer %d, vocab %d, per-GPU batch %d, dropout %s" % (
                                    "CaSE" if a.model == "case" else "Masque", a.hidden, a.enc_layers, a.passages, a.passage_len,
                                    a.query_len, a.answer_len, a.vocab, a.batch, ("off (diagnostic)" if a.no_dropout else "on") +
+                                   (", step replayed from a hipGraph" if trainer.graphs is not None else "") +
                                    (", RAGGED lengths (diagnostic: padding is counted as tokens)" if getattr(a, "ragged", False) else "")),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                    "algorithmic_tflop_per_step": round(3 * fwd * world / 1e12, 2)},
@@ -671,6 +680,7 @@ def main():
     elif world > 1 and not a.no_roofline:
         step()  # keep the ranks in lock-step with rank 0's instrumented step (it contains an all-reduce)
     if rank == 0 and world == 1 and a.mode == "train" and a.model == "case" and not a.no_north_star:
+        trainer.close()
         del trainer, opt, sched  # the training step's parameters, moments and cached operand copies are not needed any more
         torch.cuda.empty_cache()
         out["north_star"] = north_star_point(a, device)
