@@ -119,3 +119,81 @@ def test_gradsync_world2_gloo(tmp_path):
         got = r0["grads_bf16_wire"][n]
         assert torch.equal(got, r1["grads_bf16_wire"][n]), "bf16 wire: ranks disagree on " + n
         assert (got - want).abs().max() <= 1.2e-2 * want.abs().max() + 1e-8, "bf16 wire: " + n
+
+
+def _worker8(rank, world, port, out_dir):
+    """Eight ranks (the node BASELINE.json's DP = 8 names): bucket order with eight participants, two ranks on another graph
+    (Masque 'ps_train': the decoder's hooks never fire there), one abandoned step, then a clean step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from case_rg_amd.parallel import GradSync
+        from case_rg_amd.utils import fill_params
+        model = fill_params(_model(), 40 + rank).train()
+        sync = GradSync(model, bucket_mb=0.05)
+        launched = []
+        launch = sync._launch
+
+        def watched(b):
+            launched.append(next(i for i, x in enumerate(sync.buckets) if x is b))
+            launch(b)
+
+        sync._launch = watched
+        rec = {"params": {n: p.detach().clone() for n, p in model.named_parameters()}, "nbuckets": len(sync.buckets)}
+        # step 1: ranks 3 and 6 run the selection-only graph
+        method = "ps_train" if rank in (3, 6) else "train"
+        sum(l.mean() for l in model(dict(_shard(rank)), method=method)).backward()
+        sync.finish()
+        rec["order_mixed"] = list(launched)
+        rec["grads_mixed"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        # step 2: abandoned between backward and finish() on EVERY rank (collectives are in flight), then a clean step
+        del launched[:]
+        model.zero_grad()
+        sum(l.mean() for l in model(dict(_shard(rank)), method="train")).backward()
+        sync.abort()
+        assert sync._next == 0 and all(b["work"] is None and b["pending"] == len(b["items"]) for b in sync.buckets)
+        del launched[:]
+        model.zero_grad()
+        sum(l.mean() for l in model(dict(_shard(rank)), method="train")).backward()
+        sync.finish()
+        rec["order_clean"] = list(launched)
+        rec["grads_clean"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        torch.save(rec, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gradsync_world8_gloo(tmp_path):
+    """DP readiness without hardware: the bucket protocol at the world size of the target node.  Every rank issues
+    the collectives in the same (index) order whatever its graph; the averaged gradients equal the mean of the eight shard gradients
+    computed in one process (absent gradients count as zeros); an aborted step leaves no residue."""
+    world = 8
+    port = _free_port()
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    recs = [torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(world)]
+    from case_rg_amd.utils import fill_params
+    ref = fill_params(_model(), 40).train()
+    nb = recs[0]["nbuckets"]
+    assert nb > 3
+    for r in recs:
+        assert r["nbuckets"] == nb and r["order_mixed"] == list(range(nb)) and r["order_clean"] == list(range(nb)), "collectives must go out in bucket order on every rank"
+        for n, p in ref.named_parameters():
+            assert torch.equal(r["params"][n], p), "broadcast of " + n
+    want_mixed = {n: torch.zeros_like(p) for n, p in ref.named_parameters()}
+    want_clean = {n: torch.zeros_like(p) for n, p in ref.named_parameters()}
+    for rank in range(world):
+        ref.zero_grad()
+        sum(l.mean() for l in ref(dict(_shard(rank)), method="ps_train" if rank in (3, 6) else "train")).backward()
+        for n, p in ref.named_parameters():
+            if p.grad is not None:
+                want_mixed[n] += p.grad / world
+        g = _grads(ref, _shard(rank))
+        for n in g:
+            want_clean[n] += g[n] / world
+    for n in want_clean:
+        for r in recs[1:]:
+            assert torch.equal(r["grads_mixed"][n], recs[0]["grads_mixed"][n]) and torch.equal(r["grads_clean"][n], recs[0]["grads_clean"][n]), "ranks disagree on " + n
+        assert torch.allclose(recs[0]["grads_mixed"][n], want_mixed[n], rtol=2e-5, atol=2e-7), "mixed graphs: " + n
+        assert torch.allclose(recs[0]["grads_clean"][n], want_clean[n], rtol=2e-5, atol=2e-7), "after abort: " + n
