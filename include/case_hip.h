@@ -277,8 +277,9 @@ int case_softmax_bwd(const CaseSoftmaxDesc* d, const void* dy, const void* p, vo
  * Dropout acts on the probabilities with the same counter RNG / element index as case_softmax_fwd on [N, heads, Lq, Lk].
  * Backward: delta f32 [N, heads, Lq] is scratch (rowsum(dO * O), written by the call); dq / dk / dv are bf16 slices of
  * the gradient of the packed projections, addressed with the same strides as q / k / v.
- * case_attention_supported(head_dim) != 0 tells whether a head size is built (32, 64, 96, 160 = 5 x 256 / 8, 320 = 5 x 512 / 8, 480 = 5 x 768 / 8,
- * forward and backward -- case_attention_bwd_supported); other sizes use the unfused GEMM + softmax path.  Head sizes above
+ * case_attention_supported(head_dim) != 0 tells whether a head size has a fused FORWARD (32, 64, 96, 160 = 5 x 256 / 8, 320 = 5 x 512 / 8,
+ * 480 = 5 x 768 / 8), case_attention_bwd_supported whether it also has a fused backward (32, 64, 96, 160; round 6 dropped 320 / 480, whose
+ * training path is K17's saved-probability form); other sizes use the unfused GEMM + softmax path.  Head sizes above
  * 128 split the head dim over 2-3 waves per block of 32 rows (partial score tiles are exchanged through LDS).
  * case_attention_fwd_splitkv: same result for long memories with few (sequence, head) pairs (cfg 5 cross-attention: 40
  * queries x 20 480 keys): the keys are cut into `ksplit` chunks handled by different workgroups, whose unnormalised partials
