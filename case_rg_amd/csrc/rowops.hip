@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
       for (int e = 0; e < E; ++e) {
         const float gy = d[e] * g[i][e];
         s1 += gy;
-        s2 += gy * xh[e];
-        ag[i][e] += d[e] * xh[e];
+        s2 = fmaf(gy, xh[e], s2);  // explicit FMAs: the DROP2 and plain instantiations must round alike (-ffp-contract=fast may not)
+        ag[i][e] = fmaf(d[e], xh[e], ag[i][e]);
         ab[i][e] += d[e];
       }
     }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
       normalised(cur, i, xh);
       V::unpack(cur.d[i], d);
 #pragma unroll
-      for (int e = 0; e < E; ++e) o[e] = cur.rs * (d[e] * g[i][e] - m1 - xh[e] * m2);
+      for (int e = 0; e < E; ++e) o[e] = cur.rs * fmaf(-xh[e], m2, fmaf(d[e], g[i][e], -m1));
       if constexpr (HAS_ADD) {  // a second gradient of the same tensor (its residual use), summed here instead of by a separate pass
         float w[E];
         V::unpack(cur.add[i], w);
@@ -486,9 +486,9 @@ __global__ __launch_bounds__(64 * MAXW) void ln_bwd_split_kernel(const T* __rest
       for (int e = 0; e < E; ++e) {
         const float gy = d[e] * g[e];
         s1 += gy;
-        s2 += gy * xh[e];
+        s2 = fmaf(gy, xh[e], s2);
         if (real) {
-          ag[e] += d[e] * xh[e];
+          ag[e] = fmaf(d[e], xh[e], ag[e]);
           ab[e] += d[e];
         }
       }
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * MAXW) void ln_bwd_split_kernel(const T* __rest
         normalised(cur, j, xh);
         V::unpack(cur.d[j], d);
 #pragma unroll
-        for (int e = 0; e < E; ++e) o[e] = cur.rs[j] * (d[e] * g[e] - m1 - xh[e] * m2);
+        for (int e = 0; e < E; ++e) o[e] = cur.rs[j] * fmaf(-xh[e], m2, fmaf(d[e], g[e], -m1));
         if constexpr (HAS_ADD) {
           float w[E];
           V::unpack(cur.add[j], w);
