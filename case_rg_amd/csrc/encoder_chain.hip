@@ -65,6 +65,7 @@ struct Args {
   bf16_t* qkv_out;       // FULL / HEAD: [M, 1536]
   int64_t M;
   float eps2, eps1n;
+  int stagger, stagger_mode;  // two-context form: start delay (units of 4096 cycles) of every second workgroup; which ones (experiment switch)
 };
 
 // ---- weight packing -------------------------------------------------------------------------------------------------------------------------
@@ -526,6 +527,365 @@ __global__ __launch_bounds__(NTHR) void chain_kernel(const Args g) {
 #undef EC_REQUEST
 }
 
+
+// ---- TWO CONTEXTS PER CU (round 6) -----------------------------------------------------------------------------------------------------------
+// The 8-wave kernel above owns its CU: nothing runs under its epilogues (36 k of a tile's 213 k cycles), its tile I / O (23-29 k) or the
+// stage barriers, and the matrix pipes are busy 46 % of the tile.  Here a workgroup is FOUR waves on a 64-token tile (80 KiB of LDS, <= 256
+// registers), so TWO workgroups share a CU -- one wave of each per SIMD -- and one context's epilogue / tile I / O / barrier wait sits under
+// the other's K loop.  A wave owns 128 of a stage's 512 output features (8 feature blocks x 4 token blocks = the same 128 accumulator
+// registers), so per K step it streams 8 weight fragments instead of 4: every workgroup still reads the layer's whole 3 MiB, per 64
+// tokens instead of 128.  tools/l2_stream_bench.hip measured what that costs (profiles/r06_l2_stream_bench.txt): a CU draws 121-129 GB/s
+// from its XCD's L2 bare, and 87 GB/s with 4 MFMAs per fragment at 0.57 of the MFMA peak -- against 0.62 at today's 8 MFMAs per fragment:
+// the doubled stream costs the K loops 8 %, not the factor of two the per-CU rates of the micro-architecture guide suggested.
+// Same packed weights (wave w reads the streams of the 8-wave kernel's waves 2 w and 2 w + 1), same X image and swizzles, weights ONE K step
+// ahead (two register sets of 8 fragments), the Q / K / V biases from global memory into the accumulators (no LDS room: 2 x 80 KiB = 160).
+constexpr int TOK2 = 64, NTHR2 = 256, NW2 = 4, NTB2 = TOK2 / 16, NFB2 = 8;
+constexpr int X2BYTES = TOK2 * E * 2, STAT2_BYTES = TOK2 * NW2 * 8;
+enum { Q_B1 = 0, Q_B2 = 512, Q_G2 = 1024, Q_BE2 = 1536, Q_G1N = 2048, Q_BE1N = 2560, Q_FLOATS = 3072 };
+constexpr int LDS2_BYTES = X2BYTES + STAT2_BYTES + Q_FLOATS * 4;  // 79,872: two workgroups per CU
+
+template <int VARIANT>
+__global__ __launch_bounds__(NTHR2, 2) void chain2_kernel(const Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lt = l & 15, lg = l >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  float* stats = reinterpret_cast<float*>(smem + X2BYTES);
+  float* par = reinterpret_cast<float*>(smem + X2BYTES + STAT2_BYTES);
+  {
+    const float* src[6] = {g.b1, g.b2, g.g2, g.be2, g.g1n, g.be1n};
+    const int off[6] = {Q_B1, Q_B2, Q_G2, Q_BE2, Q_G1N, Q_BE1N};
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (src[i])
+        for (int k = tid; k < 512; k += NTHR2) par[off[i] + k] = src[i][k];
+  }
+  constexpr int ST0 = VARIANT == VAR_HEAD ? 3 : 0, ST1 = VARIANT == VAR_TAIL ? 3 : 6;
+  constexpr int NSTEP = (ST1 - ST0) * KSTEPS;
+  const int ntiles = (int)((g.M + TOK2 - 1) / TOK2);
+  const int n0 = 128 * wave;
+  // the two workgroups of a CU start together and would walk through the same phases together: one of them starts half a stage late
+  {
+    const bool late = g.stagger_mode == 0 ? (int)blockIdx.x >= (int)gridDim.x / 2 : (blockIdx.x & 1) != 0;
+    if (late)
+      for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
+  // weight stream: the packed streams of the 8-wave kernel's waves 2 w (feature blocks 0..3) and 2 w + 1 (4..7), one descriptor over both
+  const __amdgpu_buffer_rsrc_t wr = as_rsrc(reinterpret_cast<const char*>(g.wpk) + (int64_t)(2 * wave) * WAVE_BYTES, (uint32_t)(2 * WAVE_BYTES));
+  const int wv = l * 16;
+  int wstep = 0;
+  u32x4 wa[NFB2], wb[NFB2];
+#define C2_REQUEST(dst)                                                                                     \
+  {                                                                                                         \
+    const int so_ = ST0 * SLOT_BYTES + wstep * STEP_BYTES;                                                  \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) {                                                      \
+      dst[nb] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so_ + nb * 1024, 0);                          \
+      dst[4 + nb] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so_ + nb * 1024 + (int)WAVE_BYTES, 0);    \
+    }                                                                                                       \
+    wstep = wstep + 1 == NSTEP ? 0 : wstep + 1;                                                             \
+  }
+  C2_REQUEST(wa)
+
+  // row-layout global accesses: 32 contiguous bytes per lane, features n0 + 64 h + 16 lg .. + 15 (h = 0, 1)
+  const int v_row = (lt * E + n0 + 16 * lg) * 2, v_row3 = (lt * 3 * E + n0 + 16 * lg) * 2;
+  const int xlane = lt * 1024 + ((lg ^ (lt & 3)) << 4);
+  // accumulator-layout write: features n0 + 16 fb + 4 lg .. + 3 of row 16 tb + lt = chunk 16 wave + 2 fb + (lg >> 1), half lg & 1
+  const int xq = lt ^ (lg >> 1), xw = lt * 1024 + wave * 256 + (lg & 1) * 8;
+  // row-layout write (after to_rows of feature blocks 4 h .. 4 h + 3): chunks 16 wave + 8 h + 2 lg and + 1
+  const int xr = lt * 1024 + wave * 256;
+
+#define C2_STEP(W, KS)                                                                                                               \
+  {                                                                                                                                  \
+    bf16x8 xf[NTB2];                                                                                                                 \
+    {                                                                                                                                \
+      const char* pn = smem + xl + (((KS) ^ xh) << 6);                                                                               \
+      _Pragma("unroll") for (int tb = 0; tb < NTB2; ++tb) xf[tb] = *reinterpret_cast<const bf16x8*>(pn + tb * 16384);                 \
+    }                                                                                                                                \
+    _Pragma("unroll") for (int tb = 0; tb < NTB2; ++tb) {                                                                            \
+      _Pragma("unroll") for (int fb = 0; fb < NFB2; ++fb)                                                                            \
+        acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&W[fb]), xf[tb], acc[tb][fb], 0, 0, 0); \
+    }                                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+  }
+#define C2_KLOOP                                                                                              \
+  {                                                                                                           \
+    int xl = xlane, xh = lt >> 2;                                                                             \
+    asm volatile("" : "+v"(xl), "+v"(xh));                                                                    \
+    for (int ks = 0; ks < KSTEPS; ks += 2) {                                                                  \
+      C2_REQUEST(wb)                                                                                          \
+      C2_STEP(wa, ks)                                                                                         \
+      C2_REQUEST(wa)                                                                                          \
+      C2_STEP(wb, ks + 1)                                                                                     \
+    }                                                                                                         \
+  }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * TOK2;
+    const int rows = (int)(g.M - row0 < TOK2 ? g.M - row0 : TOK2);
+    const uint32_t tile_bytes_e = (uint32_t)rows * E * 2;
+    const __amdgpu_buffer_rsrc_t rso = as_rsrc(g.s_out + row0 * E, tile_bytes_e);
+    const __amdgpu_buffer_rsrc_t rqkv = as_rsrc(g.qkv_out ? g.qkv_out + row0 * (3 * E) : nullptr, g.qkv_out ? (uint32_t)rows * 3 * E * 2 : 0);
+    f32x4 acc[NTB2][NFB2];
+    // ---- the input tile -> X by LDS-DMA (chunks permuted on the source side) ------------------------------------------------------------
+    {
+      const i32x4 rs = make_rsrc(g.ctx + row0 * E, tile_bytes_e);
+#pragma unroll 4
+      for (int i = 0; i < TOK2 / NW2; ++i) {
+        const int r = wave * (TOK2 / NW2) + i;
+        dma16(rs, (unsigned)(r * 1024 + ((l ^ (r & 15)) << 4)), lds0 + r * 1024);
+      }
+    }
+    // ---- stage 0 accumulators: bo + s (the residual of the normed input), row layout -> accumulator layout, one 64-feature half at a time
+    if constexpr (VARIANT != VAR_HEAD) {
+      const __amdgpu_buffer_rsrc_t rres = as_rsrc(g.resid + row0 * E, tile_bytes_e);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 rr[NTB2][2];
+#pragma unroll
+        for (int tb = 0; tb < NTB2; ++tb) {
+          rr[tb][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row + h * 128, tb * 16 * E * 2, 0);
+          rr[tb][1] = __builtin_amdgcn_raw_buffer_load_b128(rres, v_row + h * 128, tb * 16 * E * 2 + 16, 0);
+        }
+        f32x4 b4[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(g.bo + n0 + 64 * h + 16 * nb + 4 * lg);
+#pragma unroll
+        for (int tb = 0; tb < NTB2; ++tb) {
+          uint32_t lo[4] = {rr[tb][0][0], rr[tb][0][2], rr[tb][1][0], rr[tb][1][2]}, hi[4] = {rr[tb][0][1], rr[tb][0][3], rr[tb][1][1], rr[tb][1][3]};
+          tr4(lo[0], lo[1], lo[2], lo[3]);
+          tr4(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            acc[tb][4 * h + nb][0] = b4[nb][0] + bf_lo(lo[nb]);
+            acc[tb][4 * h + nb][1] = b4[nb][1] + bf_hi(lo[nb]);
+            acc[tb][4 * h + nb][2] = b4[nb][2] + bf_lo(hi[nb]);
+            acc[tb][4 * h + nb][3] = b4[nb][3] + bf_hi(hi[nb]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's rows have landed
+    __syncthreads();
+
+    if constexpr (VARIANT == VAR_HEAD) {  // LayerNorm of the tile's rows in LDS (x -> s), 16 rows per wave, two at a time
+      float gam[8], bet[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(g.g1n + l * 8 + e), b = *reinterpret_cast<const f32x4*>(g.be1n + l * 8 + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gam[e + i] = a[i]; bet[e + i] = b[i]; }
+      }
+      for (int i = 0; i < TOK2 / NW2; i += 2) {
+        float x[2][8], s1[2], s2[2];
+        u32x4* p[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = wave * (TOK2 / NW2) + i + u;
+          p[u] = reinterpret_cast<u32x4*>(smem + x_off(r, l));
+          const u32x4 w = *p[u];
+          s1[u] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { x[u][2 * k] = bf_lo(w[k]); x[u][2 * k + 1] = bf_hi(w[k]); }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s1[u] += x[u][k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float mean = s1[u] * (1.f / E);
+          s2[u] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { x[u][k] -= mean; s2[u] += x[u][k] * x[u][k]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s2[0] += __shfl_xor(s2[0], o, 64); s2[1] += __shfl_xor(s2[1], o, 64); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = wave * (TOK2 / NW2) + i + u;
+          const float rstd = rsqrtf(s2[u] * (1.f / E) + g.eps1n);
+          u32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = f32x2_to_bf16x2(x[u][2 * k] * rstd * gam[2 * k] + bet[2 * k], x[u][2 * k + 1] * rstd * gam[2 * k + 1] + bet[2 * k + 1]);
+          *p[u] = o;
+          __builtin_amdgcn_raw_buffer_store_b128(o, rso, r * 1024 + l * 16, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+
+    for (int st = ST0; st < (ST1 < 3 ? ST1 : 3); ++st) {
+      if (st == 1) {
+#pragma unroll
+        for (int tb = 0; tb < NTB2; ++tb)
+#pragma unroll
+          for (int fb = 0; fb < NFB2; ++fb) acc[tb][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      C2_KLOOP
+      if (st == 1) {  // FFN1: a = gelu(acc + b1) into X where s2 stood; the s2 a lane overwrites seeds its FFN2 accumulators (b2 + s2)
+        __syncthreads();
+        int q = xq, wbase = xw;
+        asm volatile("" : "+v"(q), "+v"(wbase));
+#pragma unroll
+        for (int fb = 0; fb < NFB2; ++fb) {
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(par + Q_B1 + n0 + 16 * fb + 4 * lg);
+          const f32x4 b2v = *reinterpret_cast<const f32x4*>(par + Q_B2 + n0 + 16 * fb + 4 * lg);
+          char* px = smem + wbase + (((2 * fb) ^ q) << 4);
+#pragma unroll
+          for (int tb = 0; tb < NTB2; ++tb) {
+            u32x2* p = reinterpret_cast<u32x2*>(px + tb * 16384);
+            const u32x2 old = *p;
+            u32x2 w;
+            w[0] = f32x2_to_bf16x2(gelu_f(acc[tb][fb][0] + b1v[0]), gelu_f(acc[tb][fb][1] + b1v[1]));
+            w[1] = f32x2_to_bf16x2(gelu_f(acc[tb][fb][2] + b1v[2]), gelu_f(acc[tb][fb][3] + b1v[3]));
+            *p = w;
+            acc[tb][fb][0] = b2v[0] + bf_lo(old[0]);
+            acc[tb][fb][1] = b2v[1] + bf_hi(old[0]);
+            acc[tb][fb][2] = b2v[2] + bf_lo(old[1]);
+            acc[tb][fb][3] = b2v[3] + bf_hi(old[1]);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
+      const bool do_ln = !(VARIANT == VAR_TAIL && st == 2);
+      float mean[NTB2], rstd[NTB2];
+      if (do_ln) {
+#pragma unroll
+        for (int tb = 0; tb < NTB2; ++tb) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int fb = 0; fb < NFB2; ++fb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a += acc[tb][fb][e]; b += acc[tb][fb][e] * acc[tb][fb][e]; }
+          a += __shfl_xor(a, 16);
+          b += __shfl_xor(b, 16);
+          a += __shfl_xor(a, 32);
+          b += __shfl_xor(b, 32);
+          *reinterpret_cast<float2*>(stats + ((tb * 16 + lt) * NW2 + wave) * 2) = make_float2(a, b);
+        }
+      }
+      __syncthreads();
+      if (do_ln) {
+        const float eps = st == 0 ? g.eps2 : g.eps1n;
+#pragma unroll
+        for (int tb = 0; tb < NTB2; ++tb) {  // lane group lg reads wave lg's partial sums, two cross-lane adds finish the row
+          const float2 p = *reinterpret_cast<const float2*>(stats + ((tb * 16 + lt) * NW2 + lg) * 2);
+          float s1 = p.x, s2 = p.y;
+          s1 += __shfl_xor(s1, 16);
+          s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          mean[tb] = s1 * (1.f / E);
+          rstd[tb] = rsqrtf(fmaxf(s2 * (1.f / E) - mean[tb] * mean[tb], 0.f) + eps);
+        }
+      }
+      {
+        const float* gam = par + (st == 0 ? Q_G2 : Q_G1N);
+        const float* bet = par + (st == 0 ? Q_BE2 : Q_BE1N);
+        int q0 = lt, rbase = xr;
+        asm volatile("" : "+v"(q0), "+v"(rbase));
+        uint32_t pk[NTB2][NFB2][2];
+#pragma unroll
+        for (int fb = 0; fb < NFB2; ++fb) {
+          f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+          if (do_ln) {
+            gm = *reinterpret_cast<const f32x4*>(gam + n0 + 16 * fb + 4 * lg);
+            bt = *reinterpret_cast<const f32x4*>(bet + n0 + 16 * fb + 4 * lg);
+          }
+#pragma unroll
+          for (int tb = 0; tb < NTB2; ++tb) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = do_ln ? ((acc[tb][fb][e] - mean[tb]) * rstd[tb]) * gm[e] + bt[e] : acc[tb][fb][e];
+            pk[tb][fb][0] = f32x2_to_bf16x2(v[0], v[1]);
+            pk[tb][fb][1] = f32x2_to_bf16x2(v[2], v[3]);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q2 = q0 ^ (8 * h + 2 * lg);
+          char* pa = smem + rbase + (q2 << 4);
+          char* pb = smem + rbase + ((q2 ^ 1) << 4);
+#pragma unroll
+          for (int tb = 0; tb < NTB2; ++tb) {
+            uint32_t lo[4] = {pk[tb][4 * h][0], pk[tb][4 * h + 1][0], pk[tb][4 * h + 2][0], pk[tb][4 * h + 3][0]},
+                     hi[4] = {pk[tb][4 * h][1], pk[tb][4 * h + 1][1], pk[tb][4 * h + 2][1], pk[tb][4 * h + 3][1]};
+            u32x4 w0, w1;
+            to_rows(lo, hi, w0, w1);
+            *reinterpret_cast<u32x4*>(pa + tb * 16384) = w0;
+            *reinterpret_cast<u32x4*>(pb + tb * 16384) = w1;
+            if (st == 2) {
+              const int vo = v_row + h * 128 + tb * 16 * E * 2;
+              __builtin_amdgcn_raw_buffer_store_b128(w0, rso, vo, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(w1, rso, vo + 16, 0, 0);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int st = (ST0 > 3 ? ST0 : 3); st < ST1; ++st) {  // Q / K / V: the bias seeds the accumulators (global loads under the first weight wait)
+      {
+        const float* bias = g.bqkv + 512 * (st - 3) + n0 + 4 * lg;
+#pragma unroll
+        for (int fb = 0; fb < NFB2; ++fb) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 16 * fb);
+#pragma unroll
+          for (int tb = 0; tb < NTB2; ++tb) acc[tb][fb] = b4;
+        }
+      }
+      C2_KLOOP
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int tb = 0; tb < NTB2; ++tb) {
+          uint32_t lo[4], hi[4];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            lo[nb] = f32x2_to_bf16x2(acc[tb][4 * h + nb][0], acc[tb][4 * h + nb][1]);
+            hi[nb] = f32x2_to_bf16x2(acc[tb][4 * h + nb][2], acc[tb][4 * h + nb][3]);
+          }
+          u32x4 v0, v1;
+          to_rows(lo, hi, v0, v1);
+          const int vo = v_row3 + h * 128 + tb * 16 * 3 * E * 2 + 512 * (st - 3) * 2;  // whole offset per lane, immediate soffset (see above)
+          __builtin_amdgcn_raw_buffer_store_b128(v0, rqkv, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v1, rqkv, vo + 16, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // the last K loops are done before the next tile's DMA overwrites X
+  }
+#undef C2_KLOOP
+#undef C2_STEP
+#undef C2_REQUEST
+}
+
+template <int VARIANT>
+int launch_two_ctx(const Args& a, int cus, hipStream_t s) {
+  const int ntiles = (int)((a.M + TOK2 - 1) / TOK2);
+  const char* gm = getenv("CASE_CHAIN_TWO_CTX_WGS");  // experiment switch: workgroups per CU (default 2)
+  const int per_cu = gm ? atoi(gm) : 2;
+  const dim3 grid(ntiles < per_cu * cus ? ntiles : per_cu * cus), block(NTHR2);
+  Args b = a;
+  {
+    const char* e = getenv("CASE_CHAIN_STAGGER");
+    const char* m = getenv("CASE_CHAIN_STAGGER_MODE");
+    b.stagger = e ? atoi(e) : 2;
+    b.stagger_mode = m ? atoi(m) : 0;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chain2_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES) != hipSuccess)
+      return case_set_error(CASE_E_LAUNCH, "case_encoder_chain: cannot reserve %d bytes of LDS", LDS2_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL((chain2_kernel<VARIANT>), grid, block, LDS2_BYTES, s, b);
+  return case_check_launch("case_encoder_chain (two contexts)");
+}
+
 template <int VARIANT, bool HALF>
 int launch_one(const Args& a, int grid_max, hipStream_t s) {
   constexpr int TOKT = HALF ? TOK / 2 : TOK;
@@ -548,6 +908,9 @@ int launch_one(const Args& a, int grid_max, hipStream_t s) {
 // nobody sits out an eighth round.  CASE_CHAIN_HALVES=0 switches the split off (A/B measurements).
 template <int VARIANT>
 int launch(const Args& a, int cus, hipStream_t s) {
+  // CASE_CHAIN_TWO_CTX=1: the two-workgroups-per-CU form (round 6 A/B switch)
+  const char* two = getenv("CASE_CHAIN_TWO_CTX");  // (read per launch: tests and A/B runs flip it inside one process)
+  if (two && two[0] == '1') return launch_two_ctx<VARIANT>(a, cus, s);
   static const bool split_ok = [] {
     const char* e = getenv("CASE_CHAIN_HALVES");
     return !(e && e[0] == '0');
@@ -615,6 +978,7 @@ extern "C" int case_encoder_chain(const CaseEncoderChainDesc* d, const void* x_i
   a.M = d->rows;
   a.eps2 = d->eps_ln2;
   a.eps1n = d->eps_ln1_next;
+  a.stagger = a.stagger_mode = 0;
   const int cus = case_persistent_cus();
   switch (d->variant) {
     case enc_chain::VAR_FULL: return enc_chain::launch<enc_chain::VAR_FULL>(a, cus, (hipStream_t)stream);

@@ -26,9 +26,11 @@ def bf16_mode():
     case_rg_amd.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("two_ctx", [False, True])  # round 6: the two-workgroups-per-CU form of the kernel (64-token tiles, four waves) behind CASE_CHAIN_TWO_CTX
 @pytest.mark.parametrize("N,L,layers", [(3, 384, 2), (5, 100, 3), (1, 40, 1), (7, 384, 6), (86, 384, 2)])  # the last: 258 tiles = one whole round of full tiles + half tiles
-def test_chain_matches_the_single_launch_path_and_the_oracle(bf16_mode, N, L, layers):
+def test_chain_matches_the_single_launch_path_and_the_oracle(bf16_mode, N, L, layers, two_ctx, monkeypatch):
     import oracle
+    monkeypatch.setenv("CASE_CHAIN_TWO_CTX", "1" if two_ctx else "0")
     from case_rg_amd import _abi, ops
     from case_rg_amd.utils import fill_params
     enc = _encoder(layers, 31 + layers)
