@@ -16,7 +16,8 @@ ABI_VERSION = 600  # include/case_hip.h CASE_ABI_VERSION this binding was writte
 F32, BF16 = 0, 1
 WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
 (FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
- FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA, FEAT_POINTER_DECODE, FEAT_POINTER_HEAD, FEAT_GEMM_LN) = (1 << i for i in range(14))
+ FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA, FEAT_POINTER_DECODE, FEAT_POINTER_HEAD, FEAT_GEMM_LN, FEAT_STEP_STATE,
+ FEAT_INTERACTION) = (1 << i for i in range(16))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -47,6 +48,10 @@ class SoftmaxDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [(n, i64) for n in ("N", "heads", "Lq", "Lk", "head_dim", "ldq", "ldk", "ldv", "sq", "sk", "sv", "ldo", "so")] + \
                [("causal", i32), ("scale", f32), ("drop_p", f32), ("seed", u64), ("offset", u64), ("state", ptr)]
+
+
+class InteractionDesc(C.Structure):
+    _fields_ = [(n, i64) for n in ("n", "Lp", "Lq", "H", "eq_div")] + [("dtype", i32)]
 
 
 class AttnProductDesc(C.Structure):
@@ -120,6 +125,8 @@ SIGNATURES = {
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],
     "case_optim_adam_ema": [ptr, ptr, i64, ptr, f32, f64, f64, f64, f64, ptr, ptr],
     "case_step_advance": [ptr, u64, f64, f64, ptr],
+    "case_interaction_supported": [C.POINTER(InteractionDesc)],
+    "case_interaction_fwd": [C.POINTER(InteractionDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
 }
 
 

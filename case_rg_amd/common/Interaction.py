@@ -24,6 +24,10 @@ class Interaction(nn.Module):
     def forward(self, encode_input1, encode_input2, input1_mask, input2_mask):
         B, nq, Lq, H = encode_input1.shape
         _, P, Lp, _ = encode_input2.shape
+        needs_grad = torch.is_grad_enabled() and (encode_input1.requires_grad or encode_input2.requires_grad or self.dual_att_linear.weight.requires_grad)
+        if ops.interaction_supported(encode_input1, encode_input2, needs_grad):  # K8 as two kernels (csrc/interaction.hip)
+            G_p_q, G_q_p, _, _ = ops.interaction_fwd(encode_input1, encode_input2, input1_mask, input2_mask, self.dual_att_linear.weight)
+            return (ops.max_over_p(G_p_q) if nq != P else G_p_q), G_q_p
         if nq != P:
             assert nq == 1
             Eq = encode_input1.expand(-1, P, -1, -1)

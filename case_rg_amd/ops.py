@@ -1617,6 +1617,42 @@ def concat5_layer_norm_carry(G, gamma, beta, eps):
     return Concat5LayerNormFn.apply(e, a1, a2, valid_u8, G.detach(), gamma, beta, eps)
 
 
+# K8 as kernels (round 6, csrc/interaction.hip): scores + both softmaxes in one launch, the four products + the two concatenations in a
+# second -- instead of the 16 single launches of common/Interaction.py.  "auto": bf16, H = 512, Lq = 64, Lp a multiple of 32 up to 512,
+# no autograd (the greedy pass's encode phase, evaluation); "off": the single launches.
+INTERACTION_FUSED = os.environ.get("CASE_INTERACTION_FUSED", "auto")
+
+
+def interaction_supported(Eq, Ep, needs_grad):
+    if INTERACTION_FUSED == "off" or needs_grad or not (Eq.is_cuda and Eq.dtype == torch.bfloat16 and Ep.dtype == torch.bfloat16):
+        return False
+    if not A.lib.case_abi_features() & A.FEAT_INTERACTION:
+        return False
+    d = A.InteractionDesc()
+    d.n, d.Lp, d.Lq, d.H, d.eq_div, d.dtype = Ep.shape[0] * Ep.shape[1], Ep.shape[2], Eq.shape[2], Ep.shape[3], 1, A.BF16
+    return bool(A.lib.case_interaction_supported(d))
+
+
+def interaction_fwd(Eq, Ep, q_valid, p_valid, w):
+    """Eq [B, nq, Lq, H] (nq = 1 or P), Ep [B, P, Lp, H] bf16; masks bool [B, nq, Lq] / [B, P, Lp]; w f32 [1, 3H] ->
+    (G_p_q [B, P, Lq, 5H], G_q_p [B, P, Lp, 5H], A [B P, Lp, Lq], Bm^T [B P, Lq, Lp]).  No autograd."""
+    B, nq, Lq, H = Eq.shape
+    _, P, Lp, _ = Ep.shape
+    n = B * P
+    Eq, Ep = (t if t.is_contiguous() else t.contiguous() for t in (Eq.detach(), Ep.detach()))
+    qv, pv = _u8(q_valid), _u8(p_valid)
+    wf = w.detach().reshape(-1).float().contiguous()
+    d = A.InteractionDesc()
+    d.n, d.Lp, d.Lq, d.H, d.eq_div, d.dtype = n, Lp, Lq, H, (P if nq != P else 1), A.BF16
+    dev = Ep.device
+    a = torch.empty(n, Lp, Lq, dtype=torch.bfloat16, device=dev)
+    bt = torch.empty(n, Lq, Lp, dtype=torch.bfloat16, device=dev)
+    gqp = torch.empty(B, P, Lp, 5 * H, dtype=torch.bfloat16, device=dev)
+    gpq = torch.empty(B, P, Lq, 5 * H, dtype=torch.bfloat16, device=dev)
+    A.call("case_interaction_fwd", d, _ptr(Eq), _ptr(Ep), _ptr(qv), _ptr(pv), _ptr(wf), _ptr(a), _ptr(bt), _ptr(gqp), _ptr(gpq), _stream())
+    return gpq, gqp, a, bt
+
+
 class MaxOverPFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -66,7 +66,9 @@ enum {
   CASE_FEAT_ATTN_DECODE_MQA = 1u << 10, /* K21 case_attention_decode_mqa */
   CASE_FEAT_POINTER_DECODE = 1u << 11,  /* K22 case_pointer_attend_decode / case_additive_key_exp */
   CASE_FEAT_POINTER_HEAD = 1u << 12,    /* K23 case_pointer_head_decode */
-  CASE_FEAT_GEMM_LN = 1u << 13          /* case_gemm_ln: LayerNorm prologue of the small-problem GEMM */
+  CASE_FEAT_GEMM_LN = 1u << 13,         /* case_gemm_ln: LayerNorm prologue of the small-problem GEMM */
+  CASE_FEAT_STEP_STATE = 1u << 14,      /* ABI 600: CaseStepState on the dropout sites and the optimizer, case_step_advance */
+  CASE_FEAT_INTERACTION = 1u << 15      /* K8 case_interaction_fwd: the dual co-attention as two kernels */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -408,6 +410,24 @@ int case_highway_gate_bwd(const void* dy, const void* gnl, void* d_gnl, int64_t 
  *   bwd returns de, da1, da2.
  *   max over passages for the query side (num_q == 1): x [B, P, L, W] -> out [B, L, W], argmax int32
  * ------------------------------------------------------------------------------------------- */
+/* K8 as kernels (round 6): everything between the encoder outputs and the two 5H-wide feature tensors of common/Interaction.py:32-74 in TWO
+ * launches -- scores + both masked softmaxes, then the four products and the concatenations -- instead of 16 (two rank-1 projections, the
+ * column scaling, U and U^T, two broadcast adds, two softmaxes, four batched products, two concatenations):
+ *   U[i, j] = w1 . Eq[j] + w2 . Ep[i] + (w3 o Ep[i]) . Eq[j];  A = softmax_j U;  Bm = softmax_i U  (masked positions and all-masked rows: 0)
+ *   A1 = A Eq,  B1 = Bm^T Ep,  A2 = A B1,  B2 = Bm^T A1
+ *   g_q_p[n, i, :] = p_valid ? [Ep, A1, A2, Ep o A1, Ep o A2] : 0      g_p_q[n, j, :] = q_valid ? [Eq, B1, B2, Eq o B1, Eq o B2] : 0
+ * eq [n / eq_div, Lq, H] (eq_div = P when one query faces P passages: pair n reads query n / eq_div, common/Interaction.py:26-29), ep [n, Lp, H],
+ * q_valid [n / eq_div, Lq], p_valid [n, Lp] bytes, w f32 [3H] = dual_att_linear.weight; outputs a [n, Lp, Lq] and bt [n, Lq, Lp] (the two
+ * probability matrices, what a backward pass reads), g_q_p [n, Lp, 5H], g_p_q [n, Lq, 5H] (the max over passages of :73-74 is
+ * case_max_over_p_fwd on it).  bf16, H = 512, Lq = 64, Lp a multiple of 32 up to 512 (case_interaction_supported); CASE_E_UNSUPPORTED otherwise
+ * (run the single launches).  The row term w2 . Ep[i] rides in the product (the query operand is w3 o Eq[j] + w2, rounded to bf16 once). */
+typedef struct {
+  int64_t n, Lp, Lq, H, eq_div;
+  int32_t dtype;
+} CaseInteractionDesc;
+int case_interaction_supported(const CaseInteractionDesc* d);
+int case_interaction_fwd(const CaseInteractionDesc* d, const void* eq, const void* ep, const uint8_t* q_valid, const uint8_t* p_valid, const float* w,
+                         void* a, void* bt, void* g_q_p, void* g_p_q, case_stream_t stream);
 int case_concat5_fwd(const void* e, const void* a1, const void* a2, const uint8_t* row_valid, void* out,
                      int64_t rows, int64_t H, int32_t dtype, case_stream_t stream);
 int case_concat5_bwd(const void* d_out, const void* e, const void* a1, const void* a2, const uint8_t* row_valid,

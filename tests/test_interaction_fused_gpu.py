@@ -1,0 +1,125 @@
+"""K8 as kernels (round 6, csrc/interaction.hip; reference: common/Interaction.py:32-74): case_interaction_fwd -- scores + both masked
+softmaxes in one launch, the four products and the two 5H-wide concatenations in a second -- against (a) an f32 restatement of the
+reference's formulas on the same bf16 inputs and (b) the single-launch HIP path it replaces, for one query against P passages and for
+P against P, ragged masks (a two-token filler passage, a query row range that is all padding), Lp = 32 .. 512, more pairs than CUs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+H, LQ = 512, 64
+
+
+def _reference(Eq, Ep, qv, pv, w):
+    """common/Interaction.py:32-74 in f32 (Eq [n, Lq, H], Ep [n, Lp, H] already expanded per pair)."""
+    Eq, Ep = Eq.float(), Ep.float()
+    w1, w2, w3 = w[0, :H], w[0, H:2 * H], w[0, 2 * H:]
+    U = (Eq @ w1)[:, None, :] + (Ep @ w2)[:, :, None] + (Ep * w3) @ Eq.transpose(1, 2)
+    mask = pv[:, :, None] & qv[:, None, :]
+    U = U.masked_fill(~mask, float("-inf"))
+    A = torch.softmax(U, dim=2).nan_to_num(0.0).masked_fill(~mask, 0.0)
+    Bm = torch.softmax(U, dim=1).nan_to_num(0.0).masked_fill(~mask, 0.0)
+    A1, B1 = A @ Eq, Bm.transpose(1, 2) @ Ep
+    A2, B2 = A @ B1, Bm.transpose(1, 2) @ A1
+    Gqp = torch.cat([Ep, A1, A2, Ep * A1, Ep * A2], -1).masked_fill(~pv[:, :, None], 0.0)
+    Gpq = torch.cat([Eq, B1, B2, Eq * B1, Eq * B2], -1).masked_fill(~qv[:, :, None], 0.0)
+    return Gpq, Gqp, A, Bm.transpose(1, 2)
+
+
+@pytest.fixture
+def bf16_mode():
+    import case_rg_amd
+    case_rg_amd.set_compute_dtype(torch.bfloat16)
+    case_rg_amd.set_dropout(False)
+    yield
+    case_rg_amd.set_compute_dtype(torch.float32)
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("B,P,nq,Lp", [(2, 3, 1, 384), (2, 3, 3, 384), (1, 2, 1, 512), (3, 1, 1, 32), (30, 10, 1, 96)])
+def test_fused_interaction_matches_the_formulas_and_the_single_launches(bf16_mode, B, P, nq, Lp):
+    from case_rg_amd import _abi, ops
+    from case_rg_amd.common.Interaction import Interaction
+    g = torch.Generator().manual_seed(B * 100 + P * 10 + Lp)
+    Eq = (torch.randn(B, nq, LQ, H, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    Ep = (torch.randn(B, P, Lp, H, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    qlen = torch.randint(LQ // 2, LQ + 1, (B, nq), generator=g)
+    plen = torch.randint(max(2, Lp // 2), Lp + 1, (B, P), generator=g)
+    plen[0, P - 1] = 2  # a filler passage: [CLS][SEP] + padding
+    qv = (torch.arange(LQ)[None, None, :] < qlen[:, :, None]).to(DEV)
+    pv = (torch.arange(Lp)[None, None, :] < plen[:, :, None]).to(DEV)
+    if B > 1:
+        qv[B - 1, 0, :] = False  # a query without a token: every score of its pairs is masked
+    m = Interaction(H).to(DEV)
+    with torch.no_grad():
+        m.dual_att_linear.weight.copy_(torch.randn(1, 3 * H, generator=g).to(DEV) * 0.05)
+    calls = {}
+    raw = _abi.call
+
+    def counting(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return raw(name, *a)
+
+    with torch.no_grad():
+        _abi.call = counting
+        try:
+            got_pq, got_qp = m(Eq, Ep, qv, pv)
+        finally:
+            _abi.call = raw
+        assert calls.get("case_interaction_fwd", 0) == 1 and "case_concat5_fwd" not in calls and "case_softmax_fwd" not in calls, calls
+        gpq_raw, gqp_raw, A, Bt = ops.interaction_fwd(Eq, Ep, qv, pv, m.dual_att_linear.weight)
+        ops.INTERACTION_FUSED = "off"
+        try:
+            want_pq, want_qp = m(Eq, Ep, qv, pv)
+        finally:
+            ops.INTERACTION_FUSED = "auto"
+    n = B * P
+    Eqx = (Eq.expand(-1, P, -1, -1) if nq != P else Eq).reshape(n, LQ, H)
+    qvx = (qv.expand(-1, P, -1) if nq != P else qv).reshape(n, LQ)
+    rpq, rqp, rA, rBt = _reference(Eqx, Ep.reshape(n, Lp, H), qvx, pv.reshape(n, Lp), m.dual_att_linear.weight.detach())
+    assert torch.isfinite(got_qp.float()).all() and torch.isfinite(got_pq.float()).all()
+    # probabilities: bf16 outputs of f32 softmaxes over bf16-operand scores
+    assert (A.float() - rA).abs().max().item() <= 2e-2 and (Bt.float() - rBt).abs().max().item() <= 2e-2
+    # exact zeros where the reference has them (masked rows / columns, all-masked queries)
+    assert (A.float()[rA == 0] == 0).all() and (Bt.float()[rBt == 0] == 0).all()
+    assert (gqp_raw.reshape(n, Lp, 5 * H).float()[~pv.reshape(n, Lp)] == 0).all() and (gpq_raw.reshape(n, LQ, 5 * H).float()[~qvx] == 0).all()
+    e_qp, e_pq = _rel(gqp_raw.reshape(n, Lp, -1), rqp), _rel(gpq_raw.reshape(n, LQ, -1), rpq)
+    b_qp = _rel(want_qp.reshape(n, Lp, -1), rqp)
+    assert e_qp <= max(1e-2, 1.5 * b_qp) and e_pq <= 1e-2, (e_qp, e_pq, b_qp)
+    # the module's outputs (max over passages when one query faces P) against the single launches
+    assert _rel(got_qp, want_qp) <= 1e-2 and _rel(got_pq, want_pq) <= 1e-2, (_rel(got_qp, want_qp), _rel(got_pq, want_pq))
+    print("fused Interaction B%d P%d nq%d Lp%d: rel L2 vs f32 G_q_p %.2e (single launches %.2e), G_p_q %.2e" % (B, P, nq, Lp, e_qp, b_qp, e_pq))
+
+
+def test_training_and_f32_keep_the_single_launches(bf16_mode):
+    """The fused kernels have no autograd Function behind them and no f32 form: a forward that records a graph, or f32 inputs, run the
+    differentiable single launches."""
+    import case_rg_amd
+    from case_rg_amd import _abi
+    from case_rg_amd.common.Interaction import Interaction
+    m = Interaction(H).to(DEV)
+    Eq = torch.randn(1, 1, LQ, H, device=DEV).to(torch.bfloat16)
+    Ep = torch.randn(1, 2, 64, H, device=DEV).to(torch.bfloat16).requires_grad_()
+    qv, pv = torch.ones(1, 1, LQ, dtype=torch.bool, device=DEV), torch.ones(1, 2, 64, dtype=torch.bool, device=DEV)
+    calls = []
+    raw = _abi.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return raw(name, *a)
+
+    _abi.call = spy
+    try:
+        gpq, gqp = m(Eq, Ep, qv, pv)
+        (gqp.float().sum() + gpq.float().sum()).backward()
+        assert "case_interaction_fwd" not in calls and Ep.grad is not None
+        case_rg_amd.set_compute_dtype(torch.float32)
+        del calls[:]
+        with torch.no_grad():
+            m(Eq.float(), Ep.detach().float(), qv, pv)
+        assert "case_interaction_fwd" not in calls
+    finally:
+        _abi.call = raw
