@@ -119,6 +119,8 @@ def build(a, device):
     case_rg_amd.set_dropout(not a.no_dropout)
     if os.environ.get("CASE_ATTENTION_MODE"):  # A/B switch: "fused" / "unfused" instead of the per-head-dim policy
         case_rg_amd.ops.ATTENTION_MODE = os.environ["CASE_ATTENTION_MODE"]
+    if os.environ.get("CASE_GEMM_TILE"):  # A/B switch: force one GEMM tiling (64 / 128 / 256) instead of case_gemm's cost model
+        case_rg_amd.ops.GEMM_TILE = int(os.environ["CASE_GEMM_TILE"])
     if os.environ.get("CASE_NO_FUSED_BIAS_GRAD"):  # A/B switch: bias gradients by the separate column-sum pass
         case_rg_amd.ops.FUSE_BIAS_GRAD = False
     init_seed(123456)  # the reference's seed (CaSE/Run.py:92)

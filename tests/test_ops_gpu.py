@@ -293,6 +293,30 @@ def test_additive_scores(dt):
     _close(v.grad, vr.grad, tol, "additive dv")
 
 
+def test_additive_scores_factored_exponential_regime():
+    """The bf16 fast path of the additive attention factors 2^(w + u) = 2^w 2^u and clamps EACH prescaled argument at +-62 (csrc/attn_pointer.hip,
+    ADVICE r5): inside |wq|, |uh| <= 21.4 the scores are tanh's to bf16 noise whatever the signs -- including arguments that nearly cancel --
+    and beyond it the documented deviation appears: wq = 30, uh = -25 gives tanh(0) = 0 per feature instead of tanh(5) = 0.9999 (each factor
+    saturates, their product is 2^0).  The reference's activations (LayerNorm outputs through a xavier Linear) stay within a few units, and the
+    f32 parity path calls tanhf; this test pins where the boundary is, so that a change of the clamp shows up here."""
+    ops = _ops()
+    B, T, S, H = 1, 4, 64, 512
+    v = torch.full((H,), 1.0 / H, device=DEV)
+    for a, b, want in ((21.0, -20.0, math.tanh(1.0)), (-21.0, 20.5, math.tanh(-0.5)), (20.0, 21.0, 1.0), (-21.0, -21.0, -1.0), (3.0, -2.5, math.tanh(0.5))):
+        wq = torch.full((B, T, H), a, device=DEV)
+        uh = torch.full((B, S, H), b, device=DEV).to(torch.bfloat16)
+        s = ops.additive_scores(wq, uh, v)
+        ref = math.tanh(a + float(uh[0, 0, 0]))
+        assert abs(ref - want) < 2e-2
+        assert (s - ref).abs().max().item() <= 2e-3, (a, b, s.flatten()[0].item(), ref)
+    wq = torch.full((B, T, H), 30.0, device=DEV)
+    uh = torch.full((B, S, H), -25.0, device=DEV).to(torch.bfloat16)
+    s = ops.additive_scores(wq, uh, v)
+    assert (s.abs() <= 1e-3).all(), "outside the clamp the factored form saturates each factor: documented deviation (tanh(5) -> 0)"
+    s32 = ops.additive_scores(wq, uh.float(), v)  # the f32 path is exact
+    assert (s32 - math.tanh(5.0)).abs().max().item() <= 1e-5
+
+
 def test_embed_pos_and_pointer_and_nll():
     ops = _ops()
     from oracle import sinusoid_table
