@@ -28,6 +28,12 @@ class Interaction(nn.Module):
         if ops.interaction_supported(encode_input1, encode_input2, needs_grad):  # K8 as two kernels (csrc/interaction.hip)
             G_p_q, G_q_p, _, _ = ops.interaction_fwd(encode_input1, encode_input2, input1_mask, input2_mask, self.dual_att_linear.weight)
             return (ops.max_over_p(G_p_q) if nq != P else G_p_q), G_q_p
+        if needs_grad and ops.interaction_train_supported(encode_input1, encode_input2):  # the same kernels with an explicit backward
+            Ep_g, Ep_i = ops.fanout(encode_input2, 2)
+            G_p_q, G_q_p, A1p, A2p = ops.InteractionFn.apply(encode_input1, Ep_i, self.dual_att_linear.weight, input1_mask, input2_mask)
+            # the first TransformerBlock's LayerNorm<5H> takes its gradient straight to the pieces (ops.concat5_layer_norm_carry)
+            G_q_p._case_concat5 = (Ep_g, A1p, A2p, ops._u8(input2_mask.reshape(-1, Lp).contiguous()))
+            return (ops.max_over_p(G_p_q) if nq != P else G_p_q), G_q_p
         if nq != P:
             assert nq == 1
             Eq = encode_input1.expand(-1, P, -1, -1)

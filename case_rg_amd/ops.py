@@ -1653,6 +1653,127 @@ def interaction_fwd(Eq, Ep, q_valid, p_valid, w):
     return gpq, gqp, a, bt
 
 
+INTERACTION_TRAIN = os.environ.get("CASE_INTERACTION_TRAIN", "1") != "0"  # A/B switch: the fused forward + explicit backward in training
+
+
+class InteractionFn(Function):
+    """K8 in TRAINING: the two forward kernels (ops.interaction_fwd) with an explicit backward -- the chain rule of
+    common/Interaction.py:32-74 written out on the saved probabilities A / Bm^T and the A1 / B1 columns of the two outputs, as batched
+    GEMMs on strided views (nothing is concatenated or copied), with the score gradient formed ONCE (the single-launch forward computes U
+    and U^T by two GEMMs and autograd differentiates both).  Outputs: (G_p_q, G_q_p, A1', A2'): A1' / A2' are the [.., H:2H] / [.., 2H:3H]
+    columns of G_q_p as tensors of their own, so that the TransformerBlock's fused LayerNorm<5H> + concatenation backward
+    (ops.concat5_layer_norm_carry) can hand their gradients -- and Ep's -- over without a 5H-wide gradient tensor."""
+
+    @staticmethod
+    def forward(ctx, Eq, Ep, w, q_valid, p_valid):
+        gpq, gqp, a, bt = interaction_fwd(Eq, Ep, q_valid, p_valid, w)
+        H = Ep.shape[-1]
+        ctx.save_for_backward(Eq.detach(), Ep.detach(), w.detach(), a, bt, gqp, gpq, _u8(q_valid), _u8(p_valid))
+        a1p, a2p = gqp[..., H:2 * H], gqp[..., 2 * H:3 * H]
+        return gpq, gqp, a1p, a2p
+
+    @staticmethod
+    def backward(ctx, dgpq, dgqp, da1p, da2p):
+        Eq, Ep, w, a, bt, gqp, gpq, qv, pv = ctx.saved_tensors
+        B, nq, Lq, H = Eq.shape
+        _, P, Lp, _ = Ep.shape
+        n, dt, dev = B * P, Ep.dtype, Ep.device
+        C5 = 5 * H
+        Ep3 = Ep.reshape(n, Lp, H)
+        Ep3 = Ep3 if Ep3.is_contiguous() else Ep3.contiguous()
+        Eqx = (Eq.expand(-1, P, -1, -1) if nq != P else Eq).reshape(n, Lq, H)
+        Eqx = Eqx if Eqx.is_contiguous() else Eqx.contiguous()
+        qvx = (qv.view(B, nq, Lq).expand(-1, P, -1) if nq != P else qv.view(B, nq, Lq)).reshape(n, Lq).contiguous()
+        wf = w.reshape(-1).float().contiguous()
+        w1, w2, w3 = wf[:H], wf[H:2 * H], wf[2 * H:]
+        st = _stream()
+
+        def bg(x, y, M, N, K, lda, ldb, x_off=0, y_off=0, xk=False, yk=False, sx=None, sy=None, add=None):
+            """C[n, M, N] = op(x) op(y) (+ add), batched over the n pairs; strided operands by offset / leading dimension / batch stride."""
+            c = torch.empty(n, M, N, dtype=dt, device=dev)
+            gemm(x, y, c, M, N, K, lda, ldb, N, a_off=x_off, b_off=y_off, a_kmajor=xk, b_kmajor=yk, batch1=n,
+                 sa=(sx if sx is not None else (K * M), 0), sb=(sy if sy is not None else (K * N), 0), sc=(M * N, 0),
+                 epilogue=A.EPI_RESIDUAL if add is not None else 0, aux=add, ld_aux=N, saux=(M * N, 0))
+            return c
+
+        # ---- gradients of the concatenations ------------------------------------------------------------------------------------------------
+        dEp_parts, dEq_parts = [], []
+        dA1 = None if da1p is None else cast(da1p, dt).reshape(n, Lp, H)
+        dA2 = None if da2p is None else cast(da2p, dt).reshape(n, Lp, H)
+        if dgqp is not None:  # G_q_p consumed as a whole (not through the fused LayerNorm + concatenation backward)
+            g = cast(dgqp, dt).reshape(n * Lp, C5)
+            g = g if g.is_contiguous() else g.contiguous()
+            a1c, a2c = gqp.reshape(n * Lp, C5)[:, H:2 * H].contiguous(), gqp.reshape(n * Lp, C5)[:, 2 * H:3 * H].contiguous()
+            de, d1, d2 = (torch.empty(n * Lp, H, dtype=dt, device=dev) for _ in range(3))
+            A.call("case_concat5_bwd", _ptr(g), _ptr(Ep3), _ptr(a1c), _ptr(a2c), _ptr(pv), _ptr(de), _ptr(d1), _ptr(d2), n * Lp, H, _code(Ep3), st)
+            dEp_parts.append(de.view(n, Lp, H))
+            dA1 = d1.view(n, Lp, H) if dA1 is None else add_n([dA1, d1.view(n, Lp, H)])
+            dA2 = d2.view(n, Lp, H) if dA2 is None else add_n([dA2, d2.view(n, Lp, H)])
+        zeros_p = None
+        if dA1 is None or dA2 is None:
+            zeros_p = torch.zeros(n, Lp, H, dtype=dt, device=dev)
+            dA1 = zeros_p if dA1 is None else dA1
+            dA2 = zeros_p if dA2 is None else dA2
+        dA1 = dA1 if dA1.is_contiguous() else dA1.contiguous()
+        dA2 = dA2 if dA2.is_contiguous() else dA2.contiguous()
+        if dgpq is not None:
+            g = cast(dgpq, dt).reshape(n * Lq, C5)
+            g = g if g.is_contiguous() else g.contiguous()
+            g2 = gpq.reshape(n * Lq, C5)
+            b1c, b2c = g2[:, H:2 * H].contiguous(), g2[:, 2 * H:3 * H].contiguous()
+            de, dB1, dB2 = (torch.empty(n * Lq, H, dtype=dt, device=dev) for _ in range(3))
+            A.call("case_concat5_bwd", _ptr(g), _ptr(Eqx), _ptr(b1c), _ptr(b2c), _ptr(qvx), _ptr(de), _ptr(dB1), _ptr(dB2), n * Lq, H, _code(Eqx), st)
+            dEq_parts.append(de.view(n, Lq, H))
+            dB1, dB2 = dB1.view(n, Lq, H), dB2.view(n, Lq, H)
+        else:
+            dB1 = dB2 = torch.zeros(n, Lq, H, dtype=dt, device=dev)
+        # ---- the four products (A1 / B1 are the [H, 2H) columns of the outputs: leading dimension 5H) ----------------------------------------
+        #   A2 = A B1:  dA = dA2 B1^T,  dB1 += A^T dA2        B2 = Bm^T A1:  dBm^T = dB2 A1^T,  dA1 += Bm dB2
+        dA = bg(dA2, gpq, Lp, Lq, H, H, C5, y_off=H, sy=Lq * C5)
+        dB1t = bg(a, dA2, Lq, H, Lp, Lq, H, xk=True, yk=True, add=dB1)
+        dA1t = bg(bt, dB2, Lp, H, Lq, Lp, H, xk=True, yk=True, add=dA1)
+        dBt = bg(dB2, gqp, Lq, Lp, H, H, C5, y_off=H, sy=Lp * C5)
+        #   A1 = A Eq:  dA += dA1 Eq^T,  dEq += A^T dA1       B1 = Bm^T Ep:  dBm^T += dB1 Ep^T,  dEp += Bm dB1
+        dA = bg(dA1t, Eqx, Lp, Lq, H, H, H, add=dA)
+        dBt = bg(dB1t, Ep3, Lq, Lp, H, H, H, add=dBt)
+        dEq_parts.append(bg(a, dA1t, Lq, H, Lp, Lq, H, xk=True, yk=True))
+        dEp_parts.append(bg(bt, dB1t, Lp, H, Lq, Lp, H, xk=True, yk=True))
+        # ---- the two softmaxes share ONE score matrix ---------------------------------------------------------------------------------------
+        dUa = torch.empty(n, Lp, Lq, dtype=torch.float32, device=dev)
+        sd = _softmax_desc(n, 1, Lp, Lq, False, A.F32, _DT[dt], None)
+        A.call("case_softmax_bwd", sd, _ptr(dA), _ptr(a), _ptr(dUa), st)
+        dUb = torch.empty(n, Lq, Lp, dtype=torch.float32, device=dev)
+        sd = _softmax_desc(n, 1, Lq, Lp, False, A.F32, _DT[dt], None)
+        A.call("case_softmax_bwd", sd, _ptr(dBt), _ptr(bt), _ptr(dUb), st)
+        dU32 = dUa + dUb.transpose(1, 2)
+        dU = dU32.to(dt)
+        # ---- U = (w3 o Ep) Eq^T + w2 . Ep[i] + w1 . Eq[j] -----------------------------------------------------------------------------------
+        dEpw = bg(dU, Eqx, Lp, H, Lq, Lq, H, yk=True)
+        epw = torch.empty_like(Ep3)
+        A.call("case_scale_cols", _ptr(Ep3), _ptr(w3), _ptr(epw), n * Lp, H, _code(Ep3), st)
+        dEq_parts.append(bg(dU, epw, Lq, H, Lp, Lq, H, xk=True, yk=True))
+        dEp_s = torch.empty_like(Ep3)
+        dw1, dw2, dw3 = _zeros_like_shapes(dev, (H,), (H,), (H,))
+        A.call("case_scale_cols_bwd", _ptr(dEpw), _ptr(Ep3), _ptr(w3), _ptr(dEp_s), _ptr(dw3), n * Lp, H, _code(Ep3), st)
+        dEp_parts.append(dEp_s)
+        dap, dcq = dU32.sum(dim=2).reshape(-1).contiguous(), dU32.sum(dim=1).reshape(-1).contiguous()
+        dEp_r, dEq_r = torch.empty_like(Ep3), torch.empty_like(Eqx)
+        A.call("case_rowdot_bwd", _ptr(dap), _ptr(Ep3), _ptr(w2), _ptr(dEp_r), _ptr(dw2), None, n * Lp, H, _code(Ep3), st)
+        A.call("case_rowdot_bwd", _ptr(dcq), _ptr(Eqx), _ptr(w1), _ptr(dEq_r), _ptr(dw1), None, n * Lq, H, _code(Eqx), st)
+        dEp_parts.append(dEp_r)
+        dEq_parts.append(dEq_r)
+        dEp = add_n(dEp_parts).view(Ep.shape)
+        dEq = add_n(dEq_parts).view(B, P, Lq, H)
+        if nq != P:
+            dEq = dEq.float().sum(dim=1, keepdim=True).to(dt)
+        dw = torch.cat([dw1, dw2, dw3]).view(w.shape)
+        return dEq, dEp, dw, None, None
+
+
+def interaction_train_supported(Eq, Ep):
+    return INTERACTION_TRAIN and interaction_supported(Eq, Ep, False)
+
+
 class MaxOverPFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -85,6 +85,11 @@ class _Mode:
         case_rg_amd.set_compute_dtype(self.cfg["dtype"])
         case_rg_amd.set_dropout(False)
         ops.GEMM_TILE, ops.ATTENTION_MODE, ops.TILE_TRACE = self.cfg["tile"], self.cfg["attn"], []
+        # round 6: the "unfused" mode also keeps the Interaction as its 16 single launches (forward and autograd-composed backward); the
+        # other bf16 modes run K8's two kernels with the explicit backward
+        self._inter = (ops.INTERACTION_FUSED, ops.INTERACTION_TRAIN)
+        if self.cfg["attn"] == "unfused":
+            ops.INTERACTION_FUSED, ops.INTERACTION_TRAIN = "off", False
         self._call = _abi.call
 
         def counting(name, *a):
@@ -102,6 +107,7 @@ class _Mode:
         _abi.call = self._call
         self.tiles = ops.TILE_TRACE
         ops.GEMM_TILE, ops.ATTENTION_MODE, ops.TILE_TRACE = 0, "auto", None
+        ops.INTERACTION_FUSED, ops.INTERACTION_TRAIN = self._inter
         case_rg_amd.set_compute_dtype(torch.float32)
 
 
