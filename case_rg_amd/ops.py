@@ -1666,6 +1666,7 @@ class InteractionFn(Function):
 
     @staticmethod
     def forward(ctx, Eq, Ep, w, q_valid, p_valid):
+        ctx.set_materialize_grads(False)  # an output nobody differentiates arrives as None, not as a 5H-wide tensor of zeros
         gpq, gqp, a, bt = interaction_fwd(Eq, Ep, q_valid, p_valid, w)
         H = Ep.shape[-1]
         ctx.save_for_backward(Eq.detach(), Ep.detach(), w.detach(), a, bt, gqp, gpq, _u8(q_valid), _u8(p_valid))
