@@ -32,8 +32,11 @@ class Interaction(nn.Module):
             Ep_g, Ep_i = ops.fanout(encode_input2, 2)
             G_p_q, G_q_p, A1p, A2p = ops.InteractionFn.apply(encode_input1, Ep_i, self.dual_att_linear.weight, input1_mask, input2_mask)
             # the first TransformerBlock's LayerNorm<5H> takes its gradient straight to the pieces (ops.concat5_layer_norm_carry)
-            G_q_p._case_concat5 = (Ep_g, A1p, A2p, ops._u8(input2_mask.reshape(-1, Lp).contiguous()))
-            return (ops.max_over_p(G_p_q) if nq != P else G_p_q), G_q_p
+            # (on an ALIAS of the output: the pieces are outputs of the same autograd node, which saves G_q_p for its backward -- hung on
+            #  G_q_p itself they would close a reference cycle through that node and every step's graph would stay alive)
+            G = G_q_p.view_as(G_q_p)
+            G._case_concat5 = (Ep_g, A1p, A2p, ops._u8(input2_mask.reshape(-1, Lp).contiguous()))
+            return (ops.max_over_p(G_p_q) if nq != P else G_p_q), G
         if nq != P:
             assert nq == 1
             Eq = encode_input1.expand(-1, P, -1, -1)

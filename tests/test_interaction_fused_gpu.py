@@ -187,3 +187,25 @@ def test_f32_keeps_the_single_launches(bf16_mode):
         assert "case_interaction_fwd" not in calls
     finally:
         _abi.call = raw
+
+
+def test_training_steps_do_not_keep_their_graphs_alive(bf16_mode):
+    """The pieces handed to the block's LayerNorm are outputs of the node that saved G_q_p: hung on G_q_p itself they closed a reference
+    cycle (every step's activations stayed allocated, and a hipGraph capture after such steps crashed in hipStreamEndCapture on the stale
+    AccumulateGrad nodes).  Allocated memory must be flat from step to step."""
+    from case_rg_amd.common.Interaction import Interaction
+    from case_rg_amd.common.TransformerBlock import TransformerBlock
+    m, block = Interaction(H).to(DEV), TransformerBlock(8, 5 * H, H).to(DEV).train()
+    Eq0 = torch.randn(2, 1, LQ, H, device=DEV).to(torch.bfloat16)
+    Ep0 = torch.randn(2, 3, 128, H, device=DEV).to(torch.bfloat16)
+    qv, pv = torch.ones(2, 1, LQ, dtype=torch.bool, device=DEV), torch.ones(2, 3, 128, dtype=torch.bool, device=DEV)
+    seen = []
+    for step in range(6):
+        Eq, Ep = Eq0.clone().requires_grad_(), Ep0.clone().requires_grad_()
+        G_p_q, G_q_p = m(Eq, Ep, qv, pv)
+        (block(G_q_p, pv).float().sum() + G_p_q.float().sum()).backward()
+        m.zero_grad(), block.zero_grad()
+        del Eq, Ep, G_p_q, G_q_p
+        torch.cuda.synchronize()
+        seen.append(torch.cuda.memory_allocated())
+    assert seen[5] == seen[3] == seen[2], seen
