@@ -49,5 +49,5 @@ class TransformerBlock(nn.Module):
         n2 = self.self_attn.self_attention(n1, valid, residual=xres, p_res=0.1, ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         y = ops.ffn(n2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                     self.activation, p_inner=p, p_out=0.0)
-        y = ops.mask_rows(y, valid)
+        y = ops.mask_rows(y, valid, in_place=True)  # (y is this block's own FFN output)
         return y.reshape(B, N, L, self.output_hidden_size)

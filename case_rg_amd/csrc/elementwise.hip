@@ -26,8 +26,15 @@ template <typename T>
 __global__ void mask_rows_kernel(const T* __restrict__ x, const uint8_t* __restrict__ valid, T* __restrict__ y,
                                  int64_t rows, int64_t cols) {
   const int64_t n = rows * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    Elem<T>::st(y + i, valid[i / cols] ? Elem<T>::ld(x + i) : 0.f);
+  const bool in_place = x == y;  // only the invalid rows are touched
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool ok = valid[i / cols] != 0;
+    if (in_place) {
+      if (!ok) Elem<T>::st(y + i, 0.f);
+    } else {
+      Elem<T>::st(y + i, ok ? Elem<T>::ld(x + i) : 0.f);
+    }
+  }
 }
 
 // column sums: workgroup = 64 columns x 4 row-lanes; each workgroup walks a strided slice of the rows
@@ -148,9 +155,12 @@ __global__ void mask_rows_vec_kernel(const T* __restrict__ x, const uint8_t* __r
                                      int64_t rows, int64_t cols) {
   constexpr int E = Vec16<T>::N;
   const int64_t vpr = cols / E, nvec = rows * vpr;
+  const bool in_place = x == y;  // y aliases x: a valid row is neither read nor written -- the pass costs one flag byte per 16-byte vector
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool ok = valid[i / vpr] != 0;
+    if (in_place && ok) continue;
     float v[E];
-    if (valid[i / vpr]) Vec16<T>::load(x + i * E, v);
+    if (ok) Vec16<T>::load(x + i * E, v);
     else {
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = 0.f;

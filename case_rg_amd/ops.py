@@ -1447,8 +1447,13 @@ class MaskRowsFn(Function):
         return dx, None
 
 
-def mask_rows(x, valid):
-    """Zero x[..., r, :] where valid[..., r] is False."""
+def mask_rows(x, valid, in_place=False):
+    """Zero x[..., r, :] where valid[..., r] is False.  ``in_place`` (the caller owns x and nobody else reads it): without autograd the rows are
+    zeroed IN x -- the kernel then touches the invalid rows only (the B = 256 encode phase spent 3.3 ms per pass copying valid rows)."""
+    if in_place and not (torch.is_grad_enabled() and x.requires_grad) and x.is_contiguous():
+        C = x.shape[-1]
+        A.call("case_mask_rows", _ptr(x), _ptr(_u8(valid)), _ptr(x), x.numel() // C, C, _code(x), _stream())
+        return x
     return MaskRowsFn.apply(x, _u8(valid))
 
 

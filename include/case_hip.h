@@ -374,7 +374,8 @@ int case_add_n(const void* const* srcs, int32_t count, void* out, int64_t n, int
 /* dropout with a counter RNG keyed by (seed, offset + element index); same call regenerates the mask in bwd */
 int case_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const CaseStepState* state,
                  int32_t dtype, case_stream_t stream);
-/* zero rows whose valid flag is 0: TransformerBlock.py:31, Interaction.py:68-70 */
+/* zero rows whose valid flag is 0: TransformerBlock.py:31, Interaction.py:68-70.  y may BE x (round 6): then only the invalid rows are
+ * written and the valid ones are not touched at all (inference: a full-length batch costs one flag byte per vector instead of a copy). */
 int case_mask_rows(const void* x, const uint8_t* row_valid, void* y, int64_t rows, int64_t cols, int32_t dtype,
                    case_stream_t stream);
 /* column sums of a [rows, cols] matrix into f32 [cols] (bias gradients); out must be pre-zeroed */

@@ -1311,3 +1311,23 @@ def test_multihead_attention_takes_an_arbitrary_attn_mask(dt):
         assert split_attn_mask(None) == (False, None)
     finally:
         case_rg_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cols", [512, 100])
+def test_mask_rows_in_place_touches_only_the_invalid_rows(dt, cols):
+    """ops.mask_rows(in_place=True) without autograd zeroes the padded rows IN the tensor (case_mask_rows with y == x: the valid rows are
+    neither read nor written); with autograd it stays the out-of-place differentiable op (common/TransformerBlock.py:31 semantics)."""
+    ops = _ops()
+    x = _rand(37, cols, dt=dt, seed=1)
+    valid = torch.rand(37, device=DEV) > 0.4
+    want = x * valid[:, None].to(x.dtype)
+    with torch.no_grad():
+        y = ops.mask_rows(x.clone(), valid)
+        z0 = x.clone()
+        z = ops.mask_rows(z0, valid, in_place=True)
+    assert torch.equal(y, want) and z.data_ptr() == z0.data_ptr() and torch.equal(z, want)
+    xg = x.clone().requires_grad_()
+    out = ops.mask_rows(xg * 1.0, valid, in_place=True)
+    out.sum().backward()
+    assert torch.equal(out, want) and torch.equal(xg.grad, valid[:, None].to(x.dtype).expand_as(x))
