@@ -75,7 +75,21 @@ class StepGraphs(object):
             n = self.seen[sig] = self.seen.get(sig, 0) + 1
             if n <= self.WARM or len(self.graphs) >= self.MAX_GRAPHS:
                 return None
-            g = self.graphs[sig] = self._capture(data, method, optimizer)
+            before = config.rng_state()[1]
+            optimizer.last_stepped = []
+            try:
+                g = self.graphs[sig] = self._capture(data, method, optimizer)
+            except Exception as err:  # noqa: BLE001 -- an op the capture cannot record (a host read, an unsupported call): this shape stays eager
+                import warnings
+                warnings.warn("case_rg_amd.stepgraph: the training step could not be captured (%s: %s); running it eagerly" % (type(err).__name__, err))
+                self.disabled.add(sig)
+                for p in optimizer.last_stepped:  # host-side effects of a recording pass that executed nothing
+                    optimizer.state[p]["step"] = int(optimizer.state[p]["step"]) - 1
+                config.skip_rng(before - config.rng_state()[1])
+                optimizer.zero_grad()
+                if tr.sync is not None:
+                    tr.sync.no_sync(False)
+                return None
         elif g.opt_generation != optimizer.generation or g.shadow is not tr.ema.shadow:
             del self.graphs[sig]  # moments / EMA shadows were replaced (load_state_dict, load_checkpoint): warm up and record again
             self.seen[sig] = 0

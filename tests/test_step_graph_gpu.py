@@ -243,3 +243,33 @@ def test_evaluation_between_replays_and_checkpoint_reset(dropout_on, tmp_path):
     for s, (a, b) in enumerate(zip(eager, graph)):
         assert all(math.isfinite(x) for x in b)
         assert all(abs(x - y) <= 3e-2 * max(1.0, abs(x)) for x, y in zip(a, b)), (s, a, b)
+
+
+def test_a_step_that_cannot_be_captured_stays_eager(dropout_on):
+    """A forward that reads a device value on the host (here: a hook calling .item()) cannot be recorded: the capture attempt is abandoned with
+    a warning, its host-side effects are taken back (step counts, RNG position) and that batch shape keeps running eagerly -- same losses as a
+    trainer that never tried."""
+    import warnings
+
+    def hook(module, args, output):
+        float(output[0].sum().item())  # a host read: illegal while the stream is capturing
+
+    results = []
+    for capture in (False, True):
+        trainer, opt, sched = _tiny_trainer(torch.float32, capture=True)
+        handle = trainer.model.register_forward_hook(hook)
+        if not capture:
+            trainer.graphs = None
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            losses = [trainer.train_batch(0, _batch(s), "train", opt, sched) for s in range(5)]
+        handle.remove()
+        if capture:
+            assert trainer.graphs.replays == 0 and len(trainer.graphs.disabled) == 1
+            assert any("could not be captured" in str(w.message) for w in seen)
+        results.append((losses, sorted({int(s["step"]) for s in opt.state.values()})))
+        trainer.close()
+    (a, sa), (b, sb) = results
+    assert sa == sb == [5]
+    for x, y in zip(a, b):
+        assert all(abs(u - v) <= 2e-5 * max(1.0, abs(u)) for u, v in zip(x, y)), (x, y)
