@@ -46,6 +46,11 @@ class StepGraphs(object):
         self.graphs = {}
         self.disabled = set()
         self.replays = 0
+        # The reference's collate pads the answers of a batch to its LONGEST answer (CaSE/CaSEDataset.py:135-136), so data['response'] changes
+        # shape from batch to batch while every other tensor is fixed-size: padded here with PAD (0) up to the model's max_target_length, all
+        # batches share one captured step.  PAD targets are ignored by the loss (ignore_index 0, CaSE/Model.py:306), are masked as keys and sit
+        # behind every real position of the causal decoder: losses and gradients are unchanged (tested), the decoder just runs a few padded rows.
+        self.pad_response = getattr(trainer.model, "max_target_length", None)
 
     def reset(self):
         """Forget every captured step (after a checkpoint load or any other wholesale replacement of tensors the captures read)."""
@@ -67,6 +72,10 @@ class StepGraphs(object):
             return None
         if any(torch.is_tensor(v) and not v.is_cuda for v in data.values()):
             return None  # (a host tensor would be uploaded inside the step: not capturable)
+        r = data.get("response")
+        if self.pad_response and torch.is_tensor(r) and r.dim() == 2 and r.shape[1] < self.pad_response:
+            data = dict(data)
+            data["response"] = torch.nn.functional.pad(r, (0, self.pad_response - r.shape[1]))
         sig = _signature(data, method)
         if sig in self.disabled:
             return None

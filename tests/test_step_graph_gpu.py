@@ -273,3 +273,33 @@ def test_a_step_that_cannot_be_captured_stays_eager(dropout_on):
     assert sa == sb == [5]
     for x, y in zip(a, b):
         assert all(abs(u - v) <= 2e-5 * max(1.0, abs(u)) for u, v in zip(x, y)), (x, y)
+
+
+def test_ragged_answers_share_one_captured_step():
+    """The reference's collate pads data['response'] to the batch's longest answer (CaSE/CaSEDataset.py:135-136): the capturing trainer pads
+    it further to the model's max_target_length, so batches with answers of 5 .. 8 tokens replay ONE graph; PAD targets change neither the
+    losses nor the training trajectory (fp32, dropout off: against an eager trainer that sees the unpadded batches)."""
+    import case_rg_amd
+    from case_rg_amd import config
+    from case_rg_amd.utils import synth_batch
+
+    def batch(step):
+        return {k: v.cuda() for k, v in synth_batch(2, 3, 24, 12, 8, 300, seed=900 + step, ragged=True, model="case").items()}
+
+    lens = {batch(s)["response"].shape[1] for s in range(7)}
+    assert len(lens) >= 2, "the synthetic batches must differ in answer length for this test to mean anything"
+    runs = []
+    for capture in (False, True):
+        trainer, opt, sched = _tiny_trainer(torch.float32, capture=capture)
+        case_rg_amd.set_dropout(False)
+        losses = [trainer.train_batch(0, batch(s), "train", opt, sched) for s in range(7)]
+        if capture:
+            assert trainer.graphs.replays == 5 and len(trainer.graphs.graphs) == 1
+        runs.append((losses, {n: p.detach().clone() for n, p in trainer.model.named_parameters()}))
+        trainer.close()
+        config.set_device_state(None)
+    (la, pa), (lb, pb) = runs
+    for s, (x, y) in enumerate(zip(la, lb)):
+        assert all(abs(u - v) <= 5e-5 * max(1.0, abs(u)) for u, v in zip(x, y)), (s, x, y)
+    worst = max(((pb[n] - pa[n]).abs().max() / (pa[n].abs().max() + 1e-12)).item() for n in pa)
+    assert worst <= 5e-3, worst
