@@ -632,7 +632,7 @@ def main():
         return trainer.train_batch(0, dict(batch), "train", opt, sched)
 
     if trainer.graphs is not None:  # captured steps: two eager steps + the recording pass happen before the contract's warm-up
-        for _ in range(3):
+        for _ in range(3 + (3 if trainer.graphs.auto else 0)):  # auto: + the three timed replays after which a capture that does not pay is dropped
             step()
         assert trainer.graphs.replays >= 1, "the training step was not captured"
     for _ in range(a.warmup):
@@ -668,7 +668,7 @@ def main():
                                "query %d, answer %d, vocab %d, per-GPU batch %d, dropout %s" % (
                                    "CaSE" if a.model == "case" else "Masque", a.hidden, a.enc_layers, a.passages, a.passage_len,
                                    a.query_len, a.answer_len, a.vocab, a.batch, ("off (diagnostic)" if a.no_dropout else "on") +
-                                   (", step replayed from a hipGraph" if trainer.graphs is not None else "") +
+                                   (", step replayed from a hipGraph" if trainer.graphs is not None and trainer.graphs.graphs else "") +
                                    (", RAGGED lengths (diagnostic: padding is counted as tokens)" if getattr(a, "ragged", False) else "")),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                    "algorithmic_tflop_per_step": round(3 * fwd * world / 1e12, 2)},

@@ -41,7 +41,7 @@ def init_params(model, escape=None):
 
 class CumulativeTrainer(object):
     def __init__(self, model, tokenizer, detokenizer, local_rank, num_gpus, accumulation_steps=1, ema_rate=0.995, capture=None):
-        """``capture`` (not in the reference; default: environment CASE_STEP_GRAPH=1): replay the training step from a hipGraph
+        """``capture`` (not in the reference; True / False / "auto"; default: environment CASE_STEP_GRAPH = 1 / 0 / auto): replay the training step from a hipGraph
         recorded after two eager steps per batch shape (``case_rg_amd.stepgraph``) -- for the geometries whose step is launch-bound
         (the reference's default: hidden 256, batch 16).  The per-step scalars then live in device memory (``self.step_state``)."""
         self.local_rank = local_rank
@@ -60,14 +60,15 @@ class CumulativeTrainer(object):
         self.ema.register()
         self._loss_host = None
         if capture is None:
-            capture = os.environ.get("CASE_STEP_GRAPH", "0") == "1"
+            env = os.environ.get("CASE_STEP_GRAPH", "0")
+            capture = "auto" if env == "auto" else env == "1"
         self.step_state, self.graphs = None, None
         if capture and torch.cuda.is_available():
             from ..stepgraph import StepGraphs
             from ..stepstate import StepState
             self.step_state = StepState(next(self.model.parameters()).device)
             config.set_device_state(self.step_state.address)  # every dropout site from here on adds the device-resident base
-            self.graphs = StepGraphs(self)
+            self.graphs = StepGraphs(self, auto=capture == "auto")  # "auto": a capture is kept only where its replay is faster than the eager step
 
     def close(self):
         """Detach the device-resident step state from the process-wide dropout configuration (a capturing trainer owns it)."""
@@ -96,6 +97,13 @@ class CumulativeTrainer(object):
             if losses is not None:
                 self.accumulation_count += 1
                 return losses
+            t0 = time.perf_counter()
+            losses = self._eager_batch(epoch, data, method, optimizer, scheduler)
+            self.graphs.note_eager_ms((time.perf_counter() - t0) * 1e3)
+            return losses
+        return self._eager_batch(epoch, data, method, optimizer, scheduler)
+
+    def _eager_batch(self, epoch, data, method, optimizer, scheduler=None):
         self.accumulation_count += 1
         boundary = self.accumulation_count % self.accumulation_steps == 0
         if self.sync is not None:

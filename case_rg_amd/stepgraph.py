@@ -19,6 +19,8 @@ Anything the capture cannot serve -- another batch shape beyond ``MAX_GRAPHS``, 
 FusedAdam, parameters / optimizer state / EMA shadows that were replaced since the capture -- runs the eager step.  The captured
 memory (activations of one step) stays reserved in the graph's private pool.
 """
+import time
+
 import torch
 
 from . import config, ops
@@ -40,8 +42,14 @@ class StepGraphs(object):
     WARM = 2        # eager steps of a shape before it is captured (allocator, lazily built optimizer state, zero-arena estimate)
     MAX_GRAPHS = 4  # captured shapes kept at once (each holds one step's activations)
 
-    def __init__(self, trainer):
+    def __init__(self, trainer, auto=False):
         self.trainer = trainer
+        # ``auto``: keep a capture only if it pays -- the first replays of a shape are timed against its eager warm-up steps (wall clock;
+        # train_batch ends in a host read, so both are whole-step times) and a capture that is not at least 3 % faster is dropped (its
+        # private pool -- one step's activations -- goes back) and the shape stays eager.  GPU-bound geometries (BASELINE cfg 2) lose nothing
+        # but the trial; launch-bound ones (the reference's default geometry) keep the graph.
+        self.auto = auto
+        self.eager_ms, self.replay_ms = {}, {}
         self.seen = {}
         self.graphs = {}
         self.disabled = set()
@@ -83,6 +91,7 @@ class StepGraphs(object):
         if g is None:
             n = self.seen[sig] = self.seen.get(sig, 0) + 1
             if n <= self.WARM or len(self.graphs) >= self.MAX_GRAPHS:
+                self._sig_running_eagerly = sig  # (the trainer reports the step's wall time through note_eager_ms)
                 return None
             before = config.rng_state()[1]
             optimizer.last_stepped = []
@@ -116,6 +125,7 @@ class StepGraphs(object):
             if src is not v:
                 v.copy_(src, non_blocking=True)
         st = tr.step_state
+        t0 = time.perf_counter() if self.auto and len(self.replay_ms.get(sig, ())) < 3 else None
         base = config.begin_step()
         optimizer.stage_step(st)
         st.upload(base)
@@ -138,7 +148,22 @@ class StepGraphs(object):
         done = torch.cuda.Event()
         done.record()
         done.synchronize()
-        return tr._loss_host[:g.nloss].tolist()
+        losses = tr._loss_host[:g.nloss].tolist()
+        if t0 is not None:
+            times = self.replay_ms.setdefault(sig, [])
+            times.append((time.perf_counter() - t0) * 1e3)
+            eager = self.eager_ms.get(sig)
+            if len(times) == 3 and eager and sorted(times)[1] > 0.97 * min(eager):
+                del self.graphs[sig]  # the replay does not pay at this geometry: back to eager steps, for good
+                self.disabled.add(sig)
+        return losses
+
+    def note_eager_ms(self, ms):
+        """Wall time of the eager step the trainer just ran for the signature ``run`` declined (auto mode's yardstick)."""
+        sig = getattr(self, "_sig_running_eagerly", None)
+        if sig is not None:
+            self.eager_ms.setdefault(sig, []).append(ms)
+            self._sig_running_eagerly = None
 
     # ------------------------------------------------------------------------------------------
     def _capture(self, data, method, optimizer):

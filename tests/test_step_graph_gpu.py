@@ -303,3 +303,23 @@ def test_ragged_answers_share_one_captured_step():
         assert all(abs(u - v) <= 5e-5 * max(1.0, abs(u)) for u, v in zip(x, y)), (s, x, y)
     worst = max(((pb[n] - pa[n]).abs().max() / (pa[n].abs().max() + 1e-12)).item() for n in pa)
     assert worst <= 5e-3, worst
+
+
+@pytest.mark.parametrize("eager_ms,kept", [(1e-3, False), (1e6, True)])
+def test_auto_capture_keeps_a_graph_only_where_it_pays(dropout_on, eager_ms, kept):
+    """capture="auto": the first three replays of a shape are timed against its eager warm-up steps; a capture that is not 3 % faster is
+    dropped and the shape stays eager (the yardstick is planted here: a 1-ns eager step can never be beaten, a 1000-s one always)."""
+    trainer, opt, sched = _tiny_trainer(torch.float32, capture="auto")
+    assert trainer.graphs.auto
+    losses = []
+    for s in range(8):
+        losses.append(trainer.train_batch(0, _batch(s), "train", opt, sched))
+        for sig in trainer.graphs.eager_ms:
+            trainer.graphs.eager_ms[sig] = [eager_ms]
+    assert all(math.isfinite(x) for l in losses for x in l)
+    assert sorted({int(s_["step"]) for s_ in opt.state.values()}) == [8]
+    if kept:
+        assert len(trainer.graphs.graphs) == 1 and trainer.graphs.replays == 6 and not trainer.graphs.disabled
+    else:
+        assert not trainer.graphs.graphs and trainer.graphs.replays == 3 and len(trainer.graphs.disabled) == 1
+    trainer.close()
