@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import config, ops
-from .attention import MultiheadAttention, is_causal_mask
+from .attention import MultiheadAttention, is_causal_mask, mask_kind
 from .Highway import Highway
 from .TransformerEncoder import _check_activation, _get_clones
 
@@ -76,10 +76,26 @@ class TransformerDecoderLayer(nn.Module):
         return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
                        residual=x)
 
+    def _forward_general(self, tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask):
+        """Reference :76-89 line by line for masks the kernels' flags cannot express (a non-causal ``tgt_mask``, any ``memory_mask``): both
+        attentions through MultiheadAttention.forward's additive-mask form.  No caller on the CaSE / Masque path passes such a mask (round 6)."""
+        p = config.drop_p(self.p, self.training)
+        x = ops.layer_norm(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        a, _ = self.self_attn(x, x, x, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)
+        x = ops.add(x, ops.dropout(a, self.p, self.training))
+        x = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        a, _ = self.multihead_attn(x, memory, memory, attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)
+        x = ops.add(x, ops.dropout(a, self.p, self.training))
+        x = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return ops.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
+                       p_inner=p, p_out=p, residual=x)
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):
-        if memory_mask is not None:
-            raise NotImplementedError("memory_mask is not used on the CaSE path")
+        if memory_mask is not None or mask_kind(tgt_mask) == "general":
+            if getattr(self, "return_attention", False):
+                raise NotImplementedError("return_attention with an arbitrary tgt_mask / memory_mask is not built (no caller on the path)")
+            return self._forward_general(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask), None, None
         tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
         mv = None if memory_key_padding_mask is None else ~memory_key_padding_mask
         xb, mb, causal = tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), is_causal_mask(tgt_mask)
@@ -173,8 +189,14 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):
-        if memory_mask is not None:
-            raise NotImplementedError("memory_mask is not used on the CaSE path")
+        if memory_mask is not None or mask_kind(tgt_mask) == "general":  # the reference's loop (:189-218): every layer through its own forward
+            out = tgt
+            for layer in self.layers:
+                out = layer(out, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, tgt_key_padding_mask=tgt_key_padding_mask,
+                            memory_key_padding_mask=memory_key_padding_mask)[0]
+            if self.norm is not None:
+                out = ops.layer_norm(out, self.norm.weight, self.norm.bias, self.norm.eps)
+            return out, None, None
         tv = None if tgt_key_padding_mask is None else ~tgt_key_padding_mask
         mv = None if memory_key_padding_mask is None else ~memory_key_padding_mask
         if getattr(self, "return_attention", False):  # the reference's loop: every layer through its own forward, the last layer's weights

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import config, ops
-from .attention import MultiheadAttention, is_causal_mask
+from .attention import MultiheadAttention, mask_kind
 
 
 def _check_activation(activation):
@@ -62,9 +62,20 @@ class TransformerEncoderLayer(nn.Module):
                        self.activation, p_inner=p, p_out=p, residual=s, ln=next_norm)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
-        """src [L, N, E] (sequence first, as the reference); src_key_padding_mask [N, L] True = pad."""
+        """src [L, N, E] (sequence first, as the reference); src_key_padding_mask [N, L] True = pad.  ``src_mask``: None, the causal
+        pattern (kernel flag), or any other 2-D additive / bool mask (round 6: reference :66-75 line by line, with the attention through
+        MultiheadAttention.forward's additive-mask form -- no caller on the CaSE / Masque path passes one)."""
+        kind = mask_kind(src_mask)
+        if kind == "general":
+            p = config.drop_p(self.p, self.training)
+            s = ops.layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            a, _ = self.self_attn(s, s, s, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)
+            s = ops.add(s, ops.dropout(a, self.p, self.training))
+            s = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return ops.ffn(s, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.activation,
+                           p_inner=p, p_out=p, residual=s)
         valid = None if src_key_padding_mask is None else ~src_key_padding_mask
-        y = self.forward_batch_first(src.transpose(0, 1).contiguous(), valid, is_causal_mask(src_mask))
+        y = self.forward_batch_first(src.transpose(0, 1).contiguous(), valid, kind == "causal")
         return y.transpose(0, 1)
 
 
@@ -122,6 +133,14 @@ class TransformerEncoder(nn.Module):
         return self._layers(x, lambda layer, h, normed, nxt: layer.forward_rows(h, groups, valids, normed, nxt))
 
     def forward(self, src, mask=None, src_key_padding_mask=None):
+        kind = mask_kind(mask)
+        if kind == "general":  # the reference's loop (:19-37): every layer through its own forward with the mask
+            out = src
+            for layer in self.layers:
+                out = layer(out, src_mask=mask, src_key_padding_mask=src_key_padding_mask)
+            if self.norm is not None:
+                out = ops.layer_norm(out, self.norm.weight, self.norm.bias, self.norm.eps)
+            return out
         valid = None if src_key_padding_mask is None else ~src_key_padding_mask
-        y = self.forward_batch_first(src.transpose(0, 1).contiguous(), valid, is_causal_mask(mask))
+        y = self.forward_batch_first(src.transpose(0, 1).contiguous(), valid, kind == "causal")
         return y.transpose(0, 1)

@@ -180,6 +180,14 @@ def split_attn_mask(mask):
     return False, mask.to(torch.float32)
 
 
+def mask_kind(mask):
+    """"none" | "causal" | "general" for a layer-level ``src_mask`` / ``tgt_mask`` / ``memory_mask`` (round 6): the causal pattern keeps the
+    kernels' causal flag; anything else a 2-D mask can say goes through MultiheadAttention.forward's additive form (split_attn_mask)."""
+    if mask is None:
+        return "none"
+    return "causal" if split_attn_mask(mask)[0] else "general"
+
+
 def is_causal_mask(mask):
     """None -> False; a mask built by ``generate_square_subsequent_mask`` (tagged) -> True; any other float
     mask is checked once on the host against the causal pattern, everything else is rejected."""
