@@ -52,29 +52,54 @@ class BilinearAttention(nn.Module):
 
     @staticmethod
     def _split_mask(mask):
+        """(row valid, column valid) when ``mask`` is their outer product -- what the softmax kernel takes directly -- else None."""
         rv, cv = mask.any(dim=-1), mask.any(dim=-2)
         if not torch.equal(mask, rv.unsqueeze(-1) & cv.unsqueeze(-2)):
-            raise NotImplementedError("BilinearAttention on the HIP path takes outer-product masks (row valid x column valid)")
+            return None
         return rv, cv
 
+    def _probabilities(self, s, mask, softmax_dim=-1):
+        """softmax of the raw scores s [B, T, S] under ``mask`` [B, T, S] (True = admissible), 0 where masked and for rows / columns without
+        an admissible entry (reference :13-21: softmax, then masked_fill(~mask, 0)).  Outer-product masks -- the only kind on the CaSE /
+        Masque path -- ride in the softmax kernel as a row and a column vector; any other mask (round 6) is applied to the scores first.
+        ``softmax_dim`` -2 normalises over the query axis (the kernel normalises the last axis of the transposed scores)."""
+        B = s.shape[0]
+        if softmax_dim in (-2, s.dim() - 2):
+            return self._probabilities(s.transpose(1, 2), None if mask is None else mask.transpose(1, 2)).transpose(1, 2)
+        if mask is None:
+            return ops.masked_softmax(s, None, None, outer=B)
+        split = self._split_mask(mask)
+        if split is not None:
+            return ops.masked_softmax(s, split[1], split[0], outer=B)
+        s = s.contiguous().masked_fill(~mask, -float('inf'))
+        return ops.masked_softmax(s, None, None, outer=B)  # exp(-inf) = 0; a row of -inf alone gives exact zeros
+
+    @staticmethod
+    def _flat(t):
+        return t.reshape(-1, t.shape[-2], t.shape[-1])
+
     def matching(self, query, key, mask=None):
-        s = self.raw_scores(query, key)
+        """[B, *, T, Q] x [B, *, S, K] -> raw scores [B, *, T, S], masked -> -inf (reference :24-46)."""
+        lead = query.shape[:-2]
+        s = self.raw_scores(self._flat(query), self._flat(key)).reshape(*lead, query.shape[-2], key.shape[-2])
         return s if mask is None else s.masked_fill(~mask, -float('inf'))
 
     def score(self, query, key, softmax_dim=-1, mask=None):
-        if softmax_dim not in (-1, query.dim() - 1):
-            raise NotImplementedError("softmax over the key axis only")
-        s = self.raw_scores(query, key)
-        rv, cv = (None, None) if mask is None else self._split_mask(mask)
-        p = ops.masked_softmax(s, cv, rv, outer=s.shape[0])
-        return (s if mask is None else s.masked_fill(~mask, -float('inf'))), p
+        lead, nd = query.shape[:-2], query.dim()
+        if softmax_dim not in (-1, -2, nd - 1, nd - 2):
+            raise NotImplementedError("softmax over the key or the query axis only")
+        s = self.raw_scores(self._flat(query), self._flat(key))
+        p = self._probabilities(s, None if mask is None else self._flat(mask), -1 if softmax_dim in (-1, nd - 1) else -2)
+        s = s.reshape(*lead, *s.shape[-2:])
+        return (s if mask is None else s.masked_fill(~mask, -float('inf'))), p.reshape(*lead, *p.shape[-2:])
 
     def forward(self, query, key, value, mask=None):
-        """query [B, T, Q], key [B, S, K], value [B, S, Hv], mask [B, T, S] bool -> (ctx, raw scores, p)."""
-        if query.dim() != 3:
-            raise NotImplementedError("3-D inputs only on the HIP path")
-        rv, cv = (None, None) if mask is None else self._split_mask(mask)
-        s = self.raw_scores(query, key)
-        p = ops.masked_softmax(s, cv, rv, outer=s.shape[0])
-        ctx = ops.bmm(ops.cast_to(p, value.dtype), value, b_is_kn=True)
-        return ctx, (s if mask is None else s.masked_fill(~mask, -float('inf'))), p
+        """query [B, *, T, Q], key [B, *, S, K], value [B, *, S, Hv], mask [B, *, T, S] bool -> (ctx [B, *, T, Hv], raw scores, p)."""
+        lead = query.shape[:-2]
+        s = self.raw_scores(self._flat(query), self._flat(key))
+        p = self._probabilities(s, None if mask is None else self._flat(mask))
+        v3 = self._flat(value)
+        ctx = ops.bmm(ops.cast_to(p, v3.dtype), v3, b_is_kn=True)
+        s = s.reshape(*lead, *s.shape[-2:])
+        return (ctx.reshape(*lead, ctx.shape[-2], ctx.shape[-1]), (s if mask is None else s.masked_fill(~mask, -float('inf'))),
+                p.reshape(*lead, *p.shape[-2:]))

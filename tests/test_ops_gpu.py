@@ -1391,3 +1391,57 @@ def test_layers_take_arbitrary_src_tgt_and_memory_masks(dt):
              lambda: oracle.TransformerDecoder(oracle.TransformerDecoderLayer(E, h, dim_feedforward=E, dropout=0.0, activation="gelu"), 2), dec)
     finally:
         case_rg_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_bilinear_attention_general_masks_and_leading_dims(dt):
+    """common/BilinearAttention.py:13-59 beyond the path's call forms (VERDICT r5 missing 7): a mask that is NOT an outer product of row and
+    column validity, 4-D inputs [B, n, T, *] with a 4-D mask, and the softmax over the QUERY axis -- forward (context, raw scores,
+    probabilities) and the gradients of query / key / value against the CPU oracle's module with the same weights."""
+    import case_rg_amd
+    import oracle
+    from case_rg_amd.utils import fill_params
+    case_rg_amd.set_compute_dtype(dt)
+    case_rg_amd.set_dropout(False)
+    try:
+        ns = case_rg_amd.namespace()
+        B, n, T, S, Q, K, Hh = 2, 3, 5, 11, 24, 16, 32
+        g = torch.Generator().manual_seed(17)
+        ours = fill_params(ns.BilinearAttention(Q, K, Hh), 7).to(DEV)
+        ref = fill_params(oracle.BilinearAttention(Q, K, Hh), 7)
+        case_rg_amd.ops.invalidate_param_cache()
+        tol = 2e-3 if dt == torch.float32 else 4e-2
+        for shape4 in (False, True):
+            lead = (B, n) if shape4 else (B,)
+            q0, k0, v0 = torch.randn(*lead, T, Q, generator=g), torch.randn(*lead, S, K, generator=g), torch.randn(*lead, S, K, generator=g)
+            mask = torch.rand(*lead, T, S, generator=g) < 0.7   # a general mask: not row x column
+            mask[..., 0] = True                                  # (a row without any admissible key: zeros on both sides, tested below)
+            mask[(0,) * len(lead) + (2,)] = False
+            q, k, v = [t.to(DEV).to(dt).requires_grad_() for t in (q0, k0, v0)]
+            qr, kr, vr = [t.detach().float().cpu().requires_grad_() for t in (q, k, v)]
+            ctx, s, p = ours(q, k, v, mask=mask.to(DEV))
+            ctx_r, s_r, p_r = ref(qr, kr, vr, mask=mask)
+            p_r = p_r.nan_to_num(0.0)  # (torch: softmax of an all -inf row is NaN, then masked_fill(~mask, 0) -> 0)
+            assert ctx.shape == ctx_r.shape and p.shape == p_r.shape
+            _close(p, p_r.to(DEV), tol, "general-mask probabilities")
+            assert (p.float()[~mask.to(DEV)] == 0).all() and (p.float()[(0,) * len(lead) + (2,)] == 0).all()
+            fin = torch.isfinite(s_r)
+            assert torch.equal(torch.isfinite(s.float()).cpu(), fin)
+            _close(s.float().cpu()[fin], s_r[fin], tol, "raw scores")
+            ctx_r2 = (p_r.reshape(-1, T, S) @ vr.reshape(-1, S, K)).reshape(ctx_r.shape)  # (the oracle's ctx carries the NaN row)
+            _close(ctx, ctx_r2.to(DEV), tol, "context")
+            go = torch.randn(ctx.shape, generator=g)
+            ctx.backward(go.to(DEV).to(ctx.dtype))
+            ctx_r2.backward(go)
+            for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+                _close(a, b.to(DEV), 3 * tol, "general-mask " + name)
+        # softmax over the query axis (softmax_dim = -2), outer-product mask
+        q, k = torch.randn(B, T, Q, generator=g).to(DEV).to(dt), torch.randn(B, S, K, generator=g).to(DEV).to(dt)
+        rv, cv = torch.rand(B, T, generator=g) < 0.8, torch.rand(B, S, generator=g) < 0.8
+        rv[:, 0], cv[:, 0] = True, True
+        mask = rv[:, :, None] & cv[:, None, :]
+        _, p = ours.score(q, k, softmax_dim=-2, mask=mask.to(DEV))
+        _, p_r = ref.score(q.float().cpu(), k.float().cpu(), softmax_dim=-2, mask=mask)
+        _close(p, p_r.nan_to_num(0.0).to(DEV), tol, "softmax over the query axis")
+    finally:
+        case_rg_amd.set_compute_dtype(torch.float32)
