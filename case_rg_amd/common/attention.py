@@ -117,7 +117,7 @@ class MultiheadAttention(nn.Module):
                           p_drop=config.drop_p(p_res, self.training), ln=ln)
 
     # -- nn.MultiheadAttention-compatible call (sequence-first) ---------------------------------
-    def averaged_weights(self, query, key, key_valid=None, causal=False):
+    def averaged_weights(self, query, key, key_valid=None, causal=False, add_mask=None):
         """Head-averaged attention probabilities [N, Lq, Lk] of batch-first ``query`` [N, Lq, E] over ``key`` [N, Lk, E] -- what
         nn.MultiheadAttention returns as its second value (F.multi_head_attention_forward: softmax weights summed over the heads / heads).
         Computed on request only, by the score GEMM + masked softmax (no dropout: the reference's callers read them in eval mode, if at
@@ -126,7 +126,7 @@ class MultiheadAttention(nn.Module):
         with torch.no_grad():
             q = ops.linear(query, self.in_proj_weight[:E], self.in_proj_bias[:E])
             k = ops.linear(key, self.in_proj_weight[E:2 * E], self.in_proj_bias[E:2 * E])
-            P, _ = ops.AttentionFn._probabilities(q.contiguous(), k.contiguous(), 0, 0, h, d, ops._u8(key_valid), causal, None, 1.0 / (d ** 0.5))
+            P, _ = ops.AttentionFn._probabilities(q.contiguous(), k.contiguous(), 0, 0, h, d, ops._u8(key_valid), causal, None, 1.0 / (d ** 0.5), add_mask)
             return P.float().mean(dim=1)
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=False):
@@ -153,9 +153,7 @@ class MultiheadAttention(nn.Module):
             ctx = ops.attention(qp, kp, vp, 0, 0, 0, self.num_heads, self.head_dim, key_valid=valid, causal=causal,
                                 p_drop=config.drop_p(self.dropout, self.training), add_mask=add_mask)
             out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
-        if need_weights and add_mask is not None:
-            raise NotImplementedError("need_weights with an arbitrary attn_mask is not built (no caller on the path)")
-        weights = self.averaged_weights(q, kb, valid, causal) if need_weights else None
+        weights = self.averaged_weights(q, kb, valid, causal, add_mask) if need_weights else None
         return out.transpose(0, 1), weights
 
 
@@ -168,10 +166,10 @@ def split_attn_mask(mask):
         return False, None
     if getattr(mask, "_case_causal", False):
         return True, None
-    if mask.dim() != 2:
-        raise NotImplementedError("attn_mask must be 2-D [Lq, Lk] (per-head 3-D masks are not built)")
+    if mask.dim() not in (2, 3):
+        raise RuntimeError("attn_mask must be 2-D [Lq, Lk] or 3-D [N * heads, Lq, Lk], as nn.MultiheadAttention takes it")
     n = mask.size(0)
-    if mask.shape == (n, n) and mask.dtype != torch.bool:
+    if mask.dim() == 2 and mask.shape == (n, n) and mask.dtype != torch.bool:
         upper = torch.triu(torch.ones(n, n, dtype=torch.bool, device=mask.device), 1)
         if bool(((mask < -1e9) == upper).all()) and bool((mask.masked_select(~upper) == 0).all()):
             return True, None

@@ -1009,7 +1009,8 @@ class AttentionFn(Function):
         gemm(q_src, k_src, S, Lq, Lk, d, q_src.shape[2], k_src.shape[2], Lk, a_off=q_off, b_off=k_off, batch1=N, batch2=heads,
              sa=(Lq * q_src.shape[2], d), sb=(Lk * k_src.shape[2], d), sc=(heads * Lq * Lk, Lq * Lk), alpha=alpha)
         if add_mask is not None:
-            S.add_(add_mask.to(torch.float32).reshape(1, 1, Lq, Lk))  # glue: a broadcast add on the f32 scores (off the CaSE / Masque path)
+            # glue: a broadcast add on the f32 scores (off the CaSE / Masque path); a 3-D mask is torch's per-head form [N * heads, Lq, Lk]
+            S.add_(add_mask.to(torch.float32).reshape((1, 1, Lq, Lk) if add_mask.dim() == 2 else (S.shape[0], heads, Lq, Lk)))
         P = S if dt == torch.float32 else torch.empty(N, heads, Lq, Lk, dtype=dt, device=q_src.device)
         Pd = torch.empty_like(P) if drop is not None else P
         sd = _softmax_desc(N, heads, Lq, Lk, causal, A.F32, _DT[dt], drop)

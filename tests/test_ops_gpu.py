@@ -1303,6 +1303,20 @@ def test_multihead_attention_takes_an_arbitrary_attn_mask(dt):
             want.backward(gr.float())
             _close(q.grad, qr.grad, 2 * tol, "attn_mask dq")
             _close(kv.grad, kr.grad, 2 * tol, "attn_mask dkv")
+        # round 6: torch's per-head 3-D form [N * heads, Lq, Lk], and need_weights together with a mask (head-averaged probabilities)
+        m3 = (torch.randn(N * h, Lq, Lk, generator=g) * 2).to(DEV)
+        q = _rand(Lq, N, E, dt=dt, seed=1).requires_grad_()
+        kv = _rand(Lk, N, E, dt=dt, seed=2).requires_grad_()
+        out, w = ours(q, kv, kv, attn_mask=m3, key_padding_mask=pad, need_weights=True)
+        qr, kr = q.detach().float().requires_grad_(), kv.detach().float().requires_grad_()
+        want, w_ref = ref(qr, kr, kr, attn_mask=m3, key_padding_mask=pad, need_weights=True)
+        _close(out, want, tol, "3-D attn_mask forward")
+        _close(w, w_ref, tol, "head-averaged weights under a mask")
+        gr = _rand(Lq, N, E, dt=dt, seed=3)
+        out.backward(gr)
+        want.backward(gr.float())
+        _close(q.grad, qr.grad, 2 * tol, "3-D attn_mask dq")
+        _close(kv.grad, kr.grad, 2 * tol, "3-D attn_mask dkv")
         # the causal pattern given as a plain float matrix is still recognised and takes the fused path's flag
         from case_rg_amd.common.attention import split_attn_mask
         n = 6
