@@ -246,3 +246,29 @@ def test_split_k_heuristic_fills_whole_rounds():
     assert ops._split_for(320, 512, 1280, 2) >= 5           # not a multiple of 64: 128x128 tiling, few K tiles per split
     assert ops._split_for(30522, 512, 1280, 2) <= 2         # 956 tiles already fill the chip
     assert ops._split_for(64, 64, 64, 4) == 1               # nothing to split
+
+
+def test_lr_schedule_equals_the_installed_transformers_implementation():
+    """CaSE/Run.py:28 takes get_cosine_with_hard_restarts_schedule_with_warmup from ``transformers`` (pinned 2.1.1, not in this image: SURVEY
+    8c).  The image carries a later release of the same library; its implementation of the same function is the closest available pin of
+    the restated formula: identical learning rates over warm-up, one and three cycles, and past the end (VERDICT r5 missing 8)."""
+    transformers = pytest.importorskip("transformers")
+    ref = getattr(transformers, "get_cosine_with_hard_restarts_schedule_with_warmup", None)
+    if ref is None:
+        pytest.skip("this transformers release has no get_cosine_with_hard_restarts_schedule_with_warmup")
+    from case_rg_amd.common.schedule import get_cosine_with_hard_restarts_schedule_with_warmup as ours
+
+    def trajectory(fn, **kw):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=2.5e-4)
+        sch = fn(opt, 20, 200, **kw)
+        out = []
+        for _ in range(260):
+            out.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return out
+
+    for kw in ({}, {"num_cycles": 3}):
+        a, b = trajectory(ref, **kw), trajectory(ours, **kw)
+        assert max(abs(x - y) for x, y in zip(a, b)) <= 1e-12, kw
