@@ -1455,6 +1455,8 @@ def mask_rows(x, valid, in_place=False):
         C = x.shape[-1]
         A.call("case_mask_rows", _ptr(x), _ptr(_u8(valid)), _ptr(x), x.numel() // C, C, _code(x), _stream())
         return x
+    # (in training the out-of-place op stays: x is the output of a custom Function -- a view of its workspace -- and autograd refuses an
+    #  in-place write to such a tensor)
     return MaskRowsFn.apply(x, _u8(valid))
 
 
