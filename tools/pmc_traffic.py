@@ -30,6 +30,12 @@ def family(name):
         t = {"unsigned short": "bf16", "float": "f32"}
         return "gemm_kernel<%s,%s,%s,%s>" % (t[m.group(1)], t[m.group(2)], "Ak" if m.group(3) == "true" else "A",
                                              "Bk" if m.group(4) == "true" else "B")
+    m = re.search(r"(k8::products_kernel|k8::scores_kernel<\d>|fas_fwd_kernel<\d+|chain2_kernel<\d>)", name)  # round 6
+    if m:
+        return m.group(1)
+    m = re.search(r"chain_kernel<(\d), (?:true|false)>", name)
+    if m:
+        return "chain_kernel<%s>" % {"0": "full", "1": "tail", "2": "head"}.get(m.group(1), m.group(1))
     m = re.search(r"chain_kernel<(\d)>", name)
     if m:
         return "chain_kernel<%s>" % {"0": "full", "1": "tail", "2": "head"}.get(m.group(1), m.group(1))
