@@ -15,6 +15,12 @@ y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     if mode == "nt":
         ops.gemm(x, w, y, M, N, K, K, K, N)
+    elif mode == "nt_epi":  # bias + residual + dropout: the out-projection / FFN2 form of the encoder layers
+        from case_rg_amd import _abi as A
+        if "res" not in globals():
+            res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda")
+        ops.gemm(x, w, y, M, N, K, K, K, N, epilogue=A.EPI_BIAS_COL | A.EPI_RESIDUAL, bias_col=bias, aux=res, ld_aux=N, drop=(0.1, 1, 0))
     elif mode == "nn":
         ops.gemm(y, w, x, M, K, N, N, K, K, b_kmajor=True)
     else:  # tn: dW[N, K] = y^T x
