@@ -17,7 +17,7 @@ F32, BF16 = 0, 1
 WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
 (FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
  FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA, FEAT_POINTER_DECODE, FEAT_POINTER_HEAD, FEAT_GEMM_LN, FEAT_STEP_STATE,
- FEAT_INTERACTION) = (1 << i for i in range(16))
+ FEAT_INTERACTION, FEAT_ATTN_DECODE_APPEND) = (1 << i for i in range(17))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -80,6 +80,7 @@ SIGNATURES = {
     "case_attention_bwd_supported": [i64],
     "case_attention_decode_supported": [i64],
     "case_attention_decode": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr],
+    "case_attention_decode_append": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr],
     "case_attention_bwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_attention_scores_supported": [C.POINTER(AttnDesc)],
     "case_attention_scores_fwd": [C.POINTER(AttnDesc), ptr, ptr, ptr, ptr, ptr, ptr],

@@ -62,8 +62,11 @@ class TransformerDecoderLayer(nn.Module):
         # (bf16, width 512, a multiple of 64 sequences); the normalised rows come back as the residual of the layer's next GEMM
         fused = ops.ln_gemm_supported(x, E) and self.linear1.out_features % 64 == 0 and self.activation in ("gelu", "relu")
         qkv, x = ops.ln_linear(x, n1, sa.in_proj_weight, sa.in_proj_bias)
-        self_kv[:, t] = qkv[:, 0, E:]
-        ctx = ops.attention(qkv, self_kv, self_kv, 0, 0, E, sa.num_heads, sa.head_dim, key_valid=hist_valid)
+        if ops.decode_append_supported(qkv, self_kv, sa.num_heads, sa.head_dim):  # the cache append rides in the attention launch
+            ctx = ops.attention_decode_append(qkv, self_kv, t, sa.num_heads, sa.head_dim, key_valid=hist_valid)
+        else:
+            self_kv[:, t] = qkv[:, 0, E:]
+            ctx = ops.attention(qkv, self_kv, self_kv, 0, 0, E, sa.num_heads, sa.head_dim, key_valid=hist_valid)
         x = ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x)
         if isinstance(memory_kv, RawMemory):  # K21: attend the raw memory rows with the K / V projections absorbed into q and the output
             x = ca.cross_attention_absorbed(x, memory_kv.rows, memory_valid, ln_in=n2)

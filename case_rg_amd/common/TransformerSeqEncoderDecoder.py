@@ -196,7 +196,10 @@ class PointerDecoderCore(nn.Module):
                 copies.append(p)
             if fused_head:  # K23: vocabulary softmax, mixing, pointer scatter and argmax in one launch
                 dec_out, gen_in = self._head_parts(dec_in, x, feat)
-                gen, dist, ids = self._head_decode(dec_out, gen_in, ctxs, copies, source_map)
+                # the distributions leave the device for the LAST step only (what the caller gets back); with an EOS-aware early stop any
+                # step may turn out to be the last one
+                want = t == max_target_length - 1 or (finished is not None and not capturing)
+                gen, dist, ids = self._head_decode(dec_out, gen_in, ctxs, copies, source_map, want)
             else:
                 dec_out, gen, dist = self._head(dec_in, x, ctxs, copies, feat, source_map)
                 ids = ops.row_argmax(dist[:, -1])[0].unsqueeze(1)
@@ -213,14 +216,17 @@ class PointerDecoderCore(nn.Module):
             answer = torch.nn.functional.pad(answer, (0, max_target_length - answer.size(1)))
         return dec_out, gen, dist, answer
 
-    def _head_decode(self, dec_out, gen_in, ctxs, copies, source_map):
+    def _head_decode(self, dec_out, gen_in, ctxs, copies, source_map, want_dists=True):
         """The head of one greedy step through K23 (ops.pointer_head_decode): the two generator Linears and the mixing Linear, then ONE
         launch for softmax over V, softmax over the mixing logits, p0 x gen + the pointer scatter, and the argmax."""
         B, V = dec_out.shape[0], self.tgt_vocab_size
         h = ops.linear(gen_in, self.gen[0].weight, self.gen[0].bias)
         logits = ops.linear(h, self.gen[-2].weight, None, out_dtype=torch.float32)
         mix_logits = ops.linear(torch.cat([dec_out] + ctxs, dim=-1), self.mix.weight, self.mix.bias, out_dtype=torch.float32)
-        gen, dist, ids = ops.pointer_head_decode(logits.reshape(B, V), mix_logits.reshape(B, -1), source_map, [c.reshape(B, -1) for c in copies])
+        gen, dist, ids = ops.pointer_head_decode(logits.reshape(B, V), mix_logits.reshape(B, -1), source_map, [c.reshape(B, -1) for c in copies],
+                                                 want_gen=want_dists, want_dist=want_dists)
+        if not want_dists:
+            return None, None, ids.unsqueeze(1)
         return gen.view(B, 1, V), dist.view(B, 1, V), ids.unsqueeze(1)
 
     def _generate(self, gen_in, hidden_drop):

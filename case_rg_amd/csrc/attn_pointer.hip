@@ -305,6 +305,18 @@ __device__ __forceinline__ float row_sum4(float r0, float r1, float r2, float r3
   return t;
 }
 
+// K22's two sweeps (e^{2 uh} rows, then the value rows: 1 GB each at cfg 4, every byte once per launch) are read NON-TEMPORAL for the same
+// reason as K21's stream (attn_mqa.hip): the step's reusable data stays in the Infinity Cache.  -DCASE_STREAM_DEFAULT_POLICY: default policy (A/B).
+#ifndef CASE_STREAM_DEFAULT_POLICY
+typedef unsigned int pa_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 pa_nt_load(const void* p) {
+  const pa_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pa_u32x4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#define PA_STREAM_LOAD(P) pa_nt_load(P)
+#else
+#define PA_STREAM_LOAD(P) (*reinterpret_cast<const uint4*>(P))
+#endif
 __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
     const float* __restrict__ wq, const bf16_t* __restrict__ eu, const float* __restrict__ v, const bf16_t* __restrict__ mem,
     const uint8_t* __restrict__ col_valid, const uint8_t* __restrict__ row_valid, const float* __restrict__ prior, bf16_t* __restrict__ ctx,
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {                              \
     const int64_t j = (J0) + u * PA_WAVES;                                     \
     OK[u] = j < S && (!cv || cv[j]); /* wave-uniform */                        \
-    if (OK[u]) R[u] = *reinterpret_cast<const uint4*>(eub + j * PA_H);         \
+    if (OK[u]) R[u] = PA_STREAM_LOAD(eub + j * PA_H);                          \
   }
   PA_LOAD(raw, ok, (int64_t)wave)
   for (int64_t j0 = wave; j0 < S; j0 += 4 * PA_WAVES) {
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
     for (int u = 0; u < 4; ++u) {
       const int64_t j = j0 + u * PA_WAVES;
       pj[u] = j < S ? sc[j] : 0.f;  // wave-uniform
-      if (pj[u] != 0.f) raw[u] = *reinterpret_cast<const uint4*>(mb + j * PA_H);
+      if (pj[u] != 0.f) raw[u] = PA_STREAM_LOAD(mb + j * PA_H);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -539,7 +551,7 @@ __global__ __launch_bounds__(PH_THREADS) void pointer_head_decode_kernel(const H
   int64_t bi = V;
   for (int64_t i = tid; i < V; i += PH_THREADS) {
     const float x = row[i];
-    a.dist[b * V + i] = x;
+    if (a.dist) a.dist[b * V + i] = x;
     if (x > bv) {  // indices ascend within a thread: the first maximum is kept
       bv = x;
       bi = i;
@@ -811,7 +823,7 @@ extern "C" int case_pointer_attend_decode(const float* wq, const void* eu, const
 extern "C" int case_pointer_head_decode(const float* logits, const float* mix_logits, const uint32_t* keys, const float* const* copies,
                                         const int64_t* lens, int32_t nmem, float* gen, float* dist, int64_t* ids, float* top, int64_t B, int64_t V,
                                         int64_t S, case_stream_t stream) {
-  CASE_REQUIRE(logits && mix_logits && keys && copies && lens && dist && ids && B > 0 && V > 0 && S > 0 && nmem >= 1 && B < (1ll << 31),
+  CASE_REQUIRE(logits && mix_logits && keys && copies && lens && ids && B > 0 && V > 0 && S > 0 && nmem >= 1 && B < (1ll << 31),
                "case_pointer_head_decode: bad argument");
   if (nmem > PH_MAX_MEM || V > 36000 || S > 32768)
     return case_set_error(CASE_E_UNSUPPORTED, "case_pointer_head_decode: built for <= %d memories, V <= 36000, S <= 32768 (run the softmax / "

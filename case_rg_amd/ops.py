@@ -1105,6 +1105,33 @@ def attention_decode_mqa(qp, memory, key_valid=None):
     return out
 
 
+# The greedy step's self-attention with the cache append inside the launch (case_attention_decode_append): "auto" / "off" (A/B: the strided
+# copy into the cache + case_attention_decode)
+DECODE_APPEND = os.environ.get("CASE_DECODE_APPEND", "auto")
+
+
+def decode_append_supported(qkv, cache, heads, d):
+    return (DECODE_APPEND != "off" and qkv.is_cuda and qkv.dtype == torch.bfloat16 and cache.dtype == torch.bfloat16 and qkv.dim() == 3
+            and qkv.shape[1] == 1 and qkv.is_contiguous() and cache.is_contiguous() and not torch.is_grad_enabled()
+            and qkv.shape[0] * heads >= DECODE_MIN_PAIRS and bool(A.lib.case_abi_features() & A.FEAT_ATTN_DECODE_APPEND)
+            and bool(A.lib.case_attention_decode_supported(d)))
+
+
+def attention_decode_append(qkv, cache, t, heads, d, key_valid=None):
+    """qkv [N, 1, 3E] bf16: the packed projections of position ``t``; cache [N, Tmax, 2E] bf16: K | V of the earlier positions.  Writes the K | V
+    columns of qkv into cache[:, t] and returns the attention of the query columns over the cache rows ``key_valid`` marks (which must include
+    position t when it is to be attended) -> [N, 1, E].  One launch (no autograd: inference)."""
+    N, _, W = qkv.shape
+    E = heads * d
+    if W != 3 * E or cache.shape[0] != N or cache.shape[2] != 2 * E or not 0 <= t < cache.shape[1]:
+        raise ValueError("attention_decode_append: qkv %s against a cache %s at position %d" % (tuple(qkv.shape), tuple(cache.shape), t))
+    O = torch.empty(N, 1, E, dtype=qkv.dtype, device=qkv.device)
+    ad = _attn_desc(N, heads, 1, cache.shape[1], d, qkv, cache, cache, False, 1.0 / math.sqrt(d), None)
+    A.call("case_attention_decode_append", ad, _ptr(qkv), _ptr(cache), _ptr(cache, E), _ptr(qkv, E), _ptr(qkv, 2 * E), W, t, _ptr(_u8(key_valid)), _ptr(O),
+           _stream())
+    return O
+
+
 def attention(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, key_valid=None, causal=False, p_drop=0.0, add_mask=None):
     return AttentionFn.apply(q_src, k_src, v_src, q_off, k_off, v_off, heads, d, _u8(key_valid), causal, p_drop, add_mask)
 
@@ -1898,9 +1925,9 @@ def pointer_head_supported(source_map, V, nmem):
             and bool(A.lib.case_abi_features() & A.FEAT_POINTER_HEAD))
 
 
-def pointer_head_decode(logits, mix_logits, source_map, copies, want_gen=True):
+def pointer_head_decode(logits, mix_logits, source_map, copies, want_gen=True, want_dist=True):
     """logits f32 [B, V]; mix_logits f32 [B, 1 + nmem]; source_map a SortedSource over the concatenated memories; copies: list of f32
-    [B, len_k] pointer weights -> (gen [B, V] | None, dist [B, V], ids [B] int64) (no autograd: inference)."""
+    [B, len_k] pointer weights -> (gen [B, V] | None, dist [B, V] | None, ids [B] int64) (no autograd: inference)."""
     B, V = logits.shape
     logits = logits if logits.is_contiguous() else logits.contiguous()
     mix_logits = mix_logits.float().contiguous()
@@ -1909,7 +1936,7 @@ def pointer_head_decode(logits, mix_logits, source_map, copies, want_gen=True):
     ptrs = (C.c_void_p * n)(*[c.data_ptr() for c in cs])
     lens = (C.c_int64 * n)(*[c.shape[1] for c in cs])
     gen = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_gen else None
-    dist = torch.empty(B, V, dtype=torch.float32, device=logits.device)
+    dist = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_dist else None
     ids = torch.empty(B, dtype=torch.int64, device=logits.device)
     A.call("case_pointer_head_decode", _ptr(logits), _ptr(mix_logits), _ptr(source_map.keys), C.cast(ptrs, C.c_void_p), C.cast(lens, C.c_void_p), n,
            _ptr(gen), _ptr(dist), _ptr(ids), None, B, V, source_map.keys.shape[1], _stream())

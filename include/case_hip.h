@@ -68,7 +68,8 @@ enum {
   CASE_FEAT_POINTER_HEAD = 1u << 12,    /* K23 case_pointer_head_decode */
   CASE_FEAT_GEMM_LN = 1u << 13,         /* case_gemm_ln: LayerNorm prologue of the small-problem GEMM */
   CASE_FEAT_STEP_STATE = 1u << 14,      /* ABI 600: CaseStepState on the dropout sites and the optimizer, case_step_advance */
-  CASE_FEAT_INTERACTION = 1u << 15      /* K8 case_interaction_fwd: the dual co-attention as two kernels */
+  CASE_FEAT_INTERACTION = 1u << 15,     /* K8 case_interaction_fwd: the dual co-attention as two kernels */
+  CASE_FEAT_ATTN_DECODE_APPEND = 1u << 16 /* case_attention_decode_append: the greedy step's cache append inside the attention launch */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -310,6 +311,13 @@ int case_attention_fwd_splitkv(const CaseAttnDesc* d, const void* q, const void*
 int case_attention_decode_supported(int64_t head_dim);
 int case_attention_decode(const CaseAttnDesc* d, const void* q, const void* k, const void* v, const uint8_t* key_valid,
                           void* out, case_stream_t stream);
+/* The same step WITH the cache append (round 6; common/TransformerDecoder.py:77 at one position: the reference re-projects the whole prefix, the
+ * cached form writes position `pos`'s K / V projections into the layer's caches and attends positions <= pos): the keys / values of position
+ * `pos` are read from new_k / new_v (row n at n * new_stride elements, head h at column h * head_dim) instead of the caches and stored into
+ * k_cache / v_cache at that position by the workgroup that owns the (sequence, head) slice -- one launch instead of a strided copy + the attention.
+ * key_valid must mark `pos` as the caller wants it attended.  CASE_FEAT_ATTN_DECODE_APPEND. */
+int case_attention_decode_append(const CaseAttnDesc* d, const void* q, void* k_cache, void* v_cache, const void* new_k, const void* new_v,
+                                 int64_t new_stride, int64_t pos, const uint8_t* key_valid, void* out, case_stream_t stream);
 /* K21, the decode step's cross-attention over a LONG memory with absorbed projections (round 5): multi-query attention of 8 query rows
  * per item against the RAW memory rows [B, S, 512] (bf16), K = V = memory.  Replaces, for the layers of the passage-memory stack,
  * in_proj(q) -> case_attention_decode over the layer's cached K / V projections -> (common/TransformerDecoder.py:81-82 at one position,
@@ -464,7 +472,8 @@ int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_stream_t st
 /* K23 (round 5), the greedy step's pointer-generator head in one launch (CaSE/Model.py:34-48, :112-117; Masque/Model.py:29-44; argmax as
  * common/Utils.py:156-168, lowest index on ties):  gen = softmax(logits);  pm = softmax(mix_logits);
  *   dist[b, :] = pm[b, 0] gen[b, :] + sum_k scatter(pm[b, 1 + k] copies[k][b, :] over the source tokens);  ids[b] = argmax dist[b, :].
- * logits / gen / dist [B, V] f32 (gen nullable), mix_logits [B, 1 + nmem] f32, keys [B, S] the sorted (token << 15 | position) keys of
+ * logits / gen / dist [B, V] f32 (gen and dist nullable: a greedy step before the last one needs ids only -- 2 x B x V x 4 bytes of writes
+ * per step less), mix_logits [B, 1 + nmem] f32, keys [B, S] the sorted (token << 15 | position) keys of
  * case_source_sort over the concatenated source map, copies = nmem device pointers (host array) to [B, lens[k]] f32 weights, sum lens = S,
  * ids [B] int64, top [B] f32 (nullable) = dist[b, ids[b]].  One workgroup per row, the vocabulary row in LDS: V <= 36000, nmem <= 4,
  * S <= 32768; CASE_E_UNSUPPORTED otherwise (run case_softmax_fwd / case_copy_scatter_sorted_fwd / case_row_argmax). */

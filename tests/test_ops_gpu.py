@@ -167,6 +167,38 @@ def test_attention_decode_step(N, h, Lk):
     assert torch.count_nonzero(o[1]) == 0, "no valid key: exact zeros"
 
 
+@pytest.mark.parametrize("N,h,T,t", [(32, 8, 64, 0), (32, 8, 64, 17), (32, 8, 64, 63), (256, 8, 40, 5), (200, 1, 129, 128)])
+def test_attention_decode_append_equals_copy_then_attention(N, h, T, t):
+    """The greedy step's self-attention with the cache append inside the launch (case_attention_decode_append) against the strided copy into the
+    cache followed by case_attention_decode: the output and the WHOLE cache bit for bit -- position t written, every other row untouched --
+    with ragged history masks, a PAD token at position t (written, not attended) and a sequence without any valid position (exact zeros)."""
+    ops = _ops()
+    d, E, dt = 64, h * 64, torch.bfloat16
+    qkv = _rand(N, 1, 3 * E, dt=dt, seed=11, scale=0.5)
+    cache0 = _rand(N, T, 2 * E, dt=dt, seed=12, scale=0.5)
+    g = torch.Generator().manual_seed(13)
+    valid = (torch.rand(N, T, generator=g) > 0.2)
+    valid[:, t + 1:] = False  # positions behind t do not exist yet
+    valid[:, t] = True
+    valid[1] = False          # nothing to attend: exact zeros
+    valid[2, t] = False       # a PAD token at position t: its K / V are cached, not attended
+    valid = valid.to(DEV)
+    assert ops.decode_append_supported(qkv, cache0, h, d) or torch.is_grad_enabled()
+    with torch.no_grad():
+        assert ops.decode_append_supported(qkv, cache0, h, d)
+        a = cache0.clone()
+        o1 = ops.attention_decode_append(qkv, a, t, h, d, key_valid=valid)
+        b = cache0.clone()
+        b[:, t] = qkv[:, 0, E:]
+        o2 = ops.attention(qkv, b, b, 0, 0, E, h, d, key_valid=valid)
+    assert torch.equal(a, b), "the cache after the fused append differs from the copied one"
+    assert torch.equal(o1, o2), "attention output differs: max |diff| %.3e" % (o1.float() - o2.float()).abs().max().item()
+    assert torch.count_nonzero(o1[1]) == 0
+    with pytest.raises((ValueError, RuntimeError)):
+        with torch.no_grad():
+            ops.attention_decode_append(qkv, a, T, h, d, key_valid=valid)  # position outside the cache
+
+
 def test_softmax_masks_and_empty_rows():
     ops = _ops()
     x = _rand(2, 6, 9, seed=1).requires_grad_()
