@@ -412,25 +412,34 @@ __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   const bf16_t* mb = mem + b * S * PA_H + 8 * lane;
+  // as in sweep (1): the next four rows are requested before the current four are accumulated
+  uint4 vraw[4], vnxt[4];
+  float pj[4], pn[4];
+#define PA_VLOAD(R, P, J0)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                              \
+    const int64_t j = (J0) + u * PA_WAVES;                                     \
+    P[u] = j < S ? sc[j] : 0.f; /* wave-uniform */                             \
+    if (P[u] != 0.f) R[u] = PA_STREAM_LOAD(mb + j * PA_H);                     \
+  }
+  PA_VLOAD(vraw, pj, (int64_t)wave)
   for (int64_t j0 = wave; j0 < S; j0 += 4 * PA_WAVES) {
-    uint4 raw[4];
-    float pj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t j = j0 + u * PA_WAVES;
-      pj[u] = j < S ? sc[j] : 0.f;  // wave-uniform
-      if (pj[u] != 0.f) raw[u] = PA_STREAM_LOAD(mb + j * PA_H);
-    }
+    PA_VLOAD(vnxt, pn, j0 + 4 * PA_WAVES)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (pj[u] != 0.f) {
         float x[8];
-        Vec16<bf16_t>::unpack(raw[u], x);
+        Vec16<bf16_t>::unpack(vraw[u], x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj[u], x[e], acc[e]);
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      vraw[u] = vnxt[u];
+      pj[u] = pn[u];
+    }
   }
+#undef PA_VLOAD
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[wave * PA_H + 8 * lane + e] = acc[e];
   __syncthreads();
