@@ -17,7 +17,7 @@ F32, BF16 = 0, 1
 WS_ATTENTION_SPLITKV, WS_ATTENTION_BWD, WS_OPTIM_SUMSQ, WS_ENCODER_CHAIN_PACK, WS_GEMM_DW_SLABS = 1, 2, 3, 4, 5
 (FEAT_GEMM_256, FEAT_GEMM_SMALL, FEAT_ENCODER_CHAIN, FEAT_ATTN_SCORES, FEAT_ATTN_DECODE, FEAT_OPTIM, FEAT_ATTN_RESIDENT, FEAT_RESERVED_CUS,
  FEAT_GEMM_DW_SLABS, FEAT_DECODER_CHAIN, FEAT_ATTN_DECODE_MQA, FEAT_POINTER_DECODE, FEAT_POINTER_HEAD, FEAT_GEMM_LN, FEAT_STEP_STATE,
- FEAT_INTERACTION, FEAT_ATTN_DECODE_APPEND) = (1 << i for i in range(17))
+ FEAT_INTERACTION, FEAT_ATTN_DECODE_APPEND, FEAT_LINEAR_SKINNY) = (1 << i for i in range(18))
 EPI_BIAS_COL, EPI_BIAS_ROW, EPI_GELU, EPI_RELU = 1, 2, 4, 8
 EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ATOMIC, EPI_DROPOUT = 16, 32, 64, 128, 256
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "case_scale_cols": [ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_scale_cols_bwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_rowdot_fwd": [ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "case_linear_skinny": [ptr, ptr, i32, ptr, ptr, ptr, i64, i32, i32, ptr],
     "case_rowdot_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "case_masked_mean_fwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
     "case_masked_mean_bwd": [ptr, ptr, ptr, i64, i64, i64, i32, ptr],
@@ -120,7 +121,7 @@ SIGNATURES = {
     "case_set_reserved_cus": [i32],
     "case_attention_decode_mqa": [ptr, ptr, ptr, ptr, i64, i64, i64, i32, ptr, i64, ptr],
     "case_additive_key_exp": [ptr, ptr, i64, ptr],
-    "case_pointer_attend_decode": [ptr] * 10 + [i64, i64, i64, ptr],
+    "case_pointer_attend_decode": [ptr] * 11 + [i64, i64, i64, ptr],
     "case_pointer_head_decode": [ptr] * 5 + [i32] + [ptr] * 4 + [i64, i64, i64, ptr],
     "case_gemm_ln": [C.POINTER(GemmDesc), ptr, ptr, ptr, f32, ptr, ptr, ptr, ptr, ptr, ptr],
     "case_optim_sumsq": [ptr, ptr, i64, ptr, ptr, ptr],

@@ -28,12 +28,28 @@ class BilinearAttention(nn.Module):
         every greedy step, so it is taken once, from the f32 projection."""
         return ops.additive_key_exp(ops.linear(key, self.linear_key.weight, out_dtype=torch.float32))
 
-    def attend_decode(self, query, value, row_valid, col_valid, eu, prior=None):
-        """One decode position per sequence: query [B, 1, Q] -> (ctx [B, 1, Hv], p or, with ``prior``, p prior / (1e-8 + sum p prior) [B, 1, S])."""
+    def split_query(self, feature, x_width):
+        """For a greedy pass whose queries are [x_t | feature] with a ``feature`` [B, 1, F] that does not change over the steps (CaSE/Model.py:77-78):
+        (Wx, c) with Wx = the first ``x_width`` columns of the query projection (contiguous, compute dtype) and c = feature Wf^T + b in f32 [B, H] --
+        a step then projects x_t alone (K = x_width instead of x_width + F: the small-problem GEMM, no concatenation) and K22 adds c."""
+        W, b = self.linear_query.weight.detach(), self.linear_query.bias
+        if W.shape[1] != x_width + feature.shape[-1]:
+            raise ValueError("split_query: query width %d != %d + %d" % (W.shape[1], x_width, feature.shape[-1]))
+        wx = W[:, :x_width].to(feature.dtype).contiguous()
+        wf = W[:, x_width:].to(feature.dtype).contiguous()
+        c = ops.linear(feature, wf, b, out_dtype=torch.float32)
+        return wx, c.reshape(feature.shape[0], -1).contiguous()
+
+    def attend_decode(self, query, value, row_valid, col_valid, eu, prior=None, split=None):
+        """One decode position per sequence: query [B, 1, Q] -> (ctx [B, 1, Hv], p or, with ``prior``, p prior / (1e-8 + sum p prior) [B, 1, S]).
+        ``split`` = split_query(...): ``query`` is x_t alone."""
         B = query.shape[0]
-        wq = ops.linear(query, self.linear_query.weight, self.linear_query.bias, out_dtype=torch.float32)
+        if split is not None:
+            wq, add = ops.linear(query, split[0], None, out_dtype=torch.float32), split[1]
+        else:
+            wq, add = ops.linear(query, self.linear_query.weight, self.linear_query.bias, out_dtype=torch.float32), None
         ctx, p, copy = ops.pointer_attend_decode(wq, eu, self.v.weight.detach().reshape(-1).float(), value, col_valid,
-                                                 None if row_valid is None else row_valid.reshape(B), prior)
+                                                 None if row_valid is None else row_valid.reshape(B), prior, wq_add=add)
         return ctx.unsqueeze(1), (p if copy is None else copy).unsqueeze(1)
 
     def raw_scores(self, query, key=None, uh=None):

@@ -24,6 +24,7 @@ from .Utils import generate_square_subsequent_mask
 
 _generate_square_subsequent_mask = generate_square_subsequent_mask
 MERGED_ENCODE = os.environ.get("CASE_MERGED_ENCODE", "1") != "0"  # A/B switch of TransformerSeqEncoder.forward_many
+QUERY_SPLIT = os.environ.get("CASE_QUERY_SPLIT", "1") != "0"  # A/B switch: the greedy step projects x_t alone for the additive-attention query
 
 
 def _embedding(vocab, width, max_len=1000, emb_matrix=None):
@@ -172,6 +173,9 @@ class PointerDecoderCore(nn.Module):
             raise RuntimeError("max_target_length %d exceeds max_len %d" % (max_target_length, pos.pe.size(0)))
         ids = self._bos(B, BOS, dev)
         feat = None if feature_of is None else feature_of(1)
+        # the feature half of the additive-attention query does not change over the steps: projected once per pass (BilinearAttention.split_query)
+        splits = [self.attns[i].split_query(feat, self.hidden_size) if (QUERY_SPLIT and inference and feat is not None and cache[i]["eu"] is not None) else None
+                  for i in range(len(mems))]
         picked = []
         finished = None if self.eos_id is None else torch.zeros(B, dtype=torch.bool, device=dev)
         capturing = torch.cuda.is_current_stream_capturing()  # a captured pass cannot branch on device data: fixed T steps
@@ -184,9 +188,10 @@ class PointerDecoderCore(nn.Module):
             ctxs, copies = [], []
             for i, mem in enumerate(mems):
                 x = self.decs[i].step(x, t, self_kvs[i], hist_valid, cache[i]["kvs"], valid[i])
-                q = x if feat is None else torch.cat([x, feat], dim=-1)
+                q = x if (feat is None or splits[i] is not None) else torch.cat([x, feat], dim=-1)
                 if cache[i]["eu"] is not None:  # K22: scores, softmax, prior renormalisation and context in one launch
-                    ctx, p = self.attns[i].attend_decode(q, mem, tok_valid, valid[i], cache[i]["eu"], None if weights is None else weights[i])
+                    ctx, p = self.attns[i].attend_decode(q, mem, tok_valid, valid[i], cache[i]["eu"], None if weights is None else weights[i],
+                                                         split=splits[i])
                 else:
                     ctx, p = self.attns[i].attend(q, mem, mem, row_valid=tok_valid, col_valid=valid[i], uh=cache[i]["uh"])
                     if weights is not None:
@@ -222,7 +227,11 @@ class PointerDecoderCore(nn.Module):
         B, V = dec_out.shape[0], self.tgt_vocab_size
         h = ops.linear(gen_in, self.gen[0].weight, self.gen[0].bias)
         logits = ops.linear(h, self.gen[-2].weight, None, out_dtype=torch.float32)
-        mix_logits = ops.linear(torch.cat([dec_out] + ctxs, dim=-1), self.mix.weight, self.mix.bias, out_dtype=torch.float32)
+        parts = [dec_out] + ctxs
+        if ops.linear_skinny_supported(parts, self.mix.weight):  # the 1 + nmem mixing logits straight from the three inputs: no concatenation, no N = 3 GEMM tile
+            mix_logits = ops.linear_skinny(parts, self.mix.weight, self.mix.bias)
+        else:
+            mix_logits = ops.linear(torch.cat(parts, dim=-1), self.mix.weight, self.mix.bias, out_dtype=torch.float32)
         gen, dist, ids = ops.pointer_head_decode(logits.reshape(B, V), mix_logits.reshape(B, -1), source_map, [c.reshape(B, -1) for c in copies],
                                                  want_gen=want_dists, want_dist=want_dists)
         if not want_dists:

@@ -27,7 +27,7 @@ int case_check_launch(const char* what) {
 extern "C" int case_version(void) { return CASE_ABI_VERSION; }
 extern "C" uint32_t case_abi_features(void) {
   return CASE_FEAT_GEMM_256 | CASE_FEAT_GEMM_SMALL | CASE_FEAT_ENCODER_CHAIN | CASE_FEAT_ATTN_SCORES | CASE_FEAT_ATTN_DECODE | CASE_FEAT_OPTIM |
-         CASE_FEAT_ATTN_RESIDENT | CASE_FEAT_RESERVED_CUS | CASE_FEAT_GEMM_DW_SLABS | CASE_FEAT_ATTN_DECODE_MQA | CASE_FEAT_POINTER_DECODE | CASE_FEAT_POINTER_HEAD | CASE_FEAT_GEMM_LN | CASE_FEAT_STEP_STATE | CASE_FEAT_INTERACTION | CASE_FEAT_ATTN_DECODE_APPEND;
+         CASE_FEAT_ATTN_RESIDENT | CASE_FEAT_RESERVED_CUS | CASE_FEAT_GEMM_DW_SLABS | CASE_FEAT_ATTN_DECODE_MQA | CASE_FEAT_POINTER_DECODE | CASE_FEAT_POINTER_HEAD | CASE_FEAT_GEMM_LN | CASE_FEAT_STEP_STATE | CASE_FEAT_INTERACTION | CASE_FEAT_ATTN_DECODE_APPEND | CASE_FEAT_LINEAR_SKINNY;
 }
 extern "C" const char* case_last_error(void) { return g_err; }
 

@@ -318,7 +318,7 @@ __device__ __forceinline__ uint4 pa_nt_load(const void* p) {
 #define PA_STREAM_LOAD(P) (*reinterpret_cast<const uint4*>(P))
 #endif
 __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
-    const float* __restrict__ wq, const bf16_t* __restrict__ eu, const float* __restrict__ v, const bf16_t* __restrict__ mem,
+    const float* __restrict__ wq, const float* __restrict__ wq_add, const bf16_t* __restrict__ eu, const float* __restrict__ v, const bf16_t* __restrict__ mem,
     const uint8_t* __restrict__ col_valid, const uint8_t* __restrict__ row_valid, const float* __restrict__ prior, bf16_t* __restrict__ ctx,
     float* __restrict__ p_out, float* __restrict__ copy_out, const int64_t S) {
   extern __shared__ __attribute__((aligned(16))) float pa_smem[];
@@ -333,6 +333,13 @@ __global__ __launch_bounds__(64 * PA_WAVES) void pointer_attend_decode_kernel(
     float w8[8];
     Vec16<float>::load(wq + b * PA_H + 8 * lane, *reinterpret_cast<float(*)[4]>(w8));
     Vec16<float>::load(wq + b * PA_H + 8 * lane + 4, *reinterpret_cast<float(*)[4]>(w8 + 4));
+    if (wq_add) {  // the step-invariant part of the query projection (its feature columns and the bias), kept in f32
+      float c8[8];
+      Vec16<float>::load(wq_add + b * PA_H + 8 * lane, *reinterpret_cast<float(*)[4]>(c8));
+      Vec16<float>::load(wq_add + b * PA_H + 8 * lane + 4, *reinterpret_cast<float(*)[4]>(c8 + 4));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w8[e] += c8[e];
+    }
     Vec16<float>::load(v + 8 * lane, *reinterpret_cast<float(*)[4]>(vv));
     Vec16<float>::load(v + 8 * lane + 4, *reinterpret_cast<float(*)[4]>(vv + 4));
 #pragma unroll
@@ -805,7 +812,7 @@ extern "C" int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_
   return case_check_launch("case_additive_key_exp");
 }
 
-extern "C" int case_pointer_attend_decode(const float* wq, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
+extern "C" int case_pointer_attend_decode(const float* wq, const float* wq_add, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
                                           const uint8_t* row_valid, const float* prior, void* ctx, float* p, float* copy, int64_t B, int64_t S,
                                           int64_t H, case_stream_t stream) {
   CASE_REQUIRE(wq && eu && v && value && ctx && p && B > 0 && S > 0 && B < (1ll << 31) && (copy != nullptr) == (prior != nullptr),
@@ -813,7 +820,7 @@ extern "C" int case_pointer_attend_decode(const float* wq, const void* eu, const
   if (H != PA_H || S > 28000)
     return case_set_error(CASE_E_UNSUPPORTED, "case_pointer_attend_decode: built for H = %d and S <= 28000 (run case_additive_scores_fwd + "
                                               "case_softmax_fwd + case_gemm)", PA_H);
-  for (const void* q : {(const void*)wq, eu, (const void*)v, value})
+  for (const void* q : {(const void*)wq, (const void*)wq_add, eu, (const void*)v, value})
     CASE_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "case_pointer_attend_decode: tensors must be 16-byte aligned");
   const size_t lds = (size_t)(((S + 3) & ~(int64_t)3) + PA_WAVES * PA_H) * sizeof(float);
   static bool attr = false;
@@ -823,7 +830,7 @@ extern "C" int case_pointer_attend_decode(const float* wq, const void* eu, const
       return case_set_error(CASE_E_LAUNCH, "case_pointer_attend_decode: cannot reserve LDS");
     attr = true;
   }
-  hipLaunchKernelGGL(pointer_attend_decode_kernel, dim3((unsigned)B), dim3(64 * PA_WAVES), lds, (hipStream_t)stream, wq,
+  hipLaunchKernelGGL(pointer_attend_decode_kernel, dim3((unsigned)B), dim3(64 * PA_WAVES), lds, (hipStream_t)stream, wq, wq_add,
                      reinterpret_cast<const bf16_t*>(eu), v, reinterpret_cast<const bf16_t*>(value), col_valid, row_valid, prior,
                      reinterpret_cast<bf16_t*>(ctx), p, copy, S);
   return case_check_launch("case_pointer_attend_decode");

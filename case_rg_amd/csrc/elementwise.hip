@@ -186,6 +186,69 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x
   }
 }
 
+// ---- few-output linear over a column-wise CONCATENATION of up to four inputs (the greedy step's mixing logits: Linear(3H, 1 + nmem) on
+// [dec_out | ctx_q | ctx_p], CaSE/Model.py:116, Masque/Model.py:42): y[r, o] = sum_k x_k[r, :] . w[o, off_k : off_k + width_k] + b[o].
+// One wave per row, NOUT <= 8 accumulators per lane, f32 weights; neither the concatenated row nor an N = 3 GEMM tile exists.
+struct SkinnyArgs {
+  const void* x[4];
+  int64_t width[4];
+  const float* w; const float* b; float* y;
+  int64_t rows, cols;
+  int nseg, nout;
+};
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const SkinnyArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  constexpr int NV = Vec16<T>::N;  // elements per 16-byte load: 4 (f32) or 8 (bf16)
+  for (int64_t r = wave; r < a.rows; r += nwaves) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < a.nseg) {
+        const T* xr = reinterpret_cast<const T*>(a.x[k]) + r * a.width[k];
+        if constexpr (VEC) {  // every width a multiple of NV, every base 16-byte aligned: one 16-byte load of x and NV / 4 of each weight row per step
+#pragma unroll 2
+          for (int64_t c = (int64_t)lane * NV; c < a.width[k]; c += 64 * NV) {
+            float xv[NV];
+            Vec16<T>::load(xr + c, xv);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+              if (o < a.nout) {
+                const float* wr = a.w + o * a.cols + off + c;
+#pragma unroll
+                for (int q = 0; q < NV / 4; ++q) {
+                  const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q);
+                  acc[o] = fmaf(xv[4 * q], wv.x, acc[o]);
+                  acc[o] = fmaf(xv[4 * q + 1], wv.y, acc[o]);
+                  acc[o] = fmaf(xv[4 * q + 2], wv.z, acc[o]);
+                  acc[o] = fmaf(xv[4 * q + 3], wv.w, acc[o]);
+                }
+              }
+            }
+          }
+        } else {
+          for (int64_t c = lane; c < a.width[k]; c += 64) {
+            const float xv = Elem<T>::ld(xr + c);
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+              if (o < a.nout) acc[o] = fmaf(xv, a.w[o * a.cols + off + c], acc[o]);
+          }
+        }
+        off += a.width[k];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      if (o < a.nout) {
+        const float t = wave_sum(acc[o]);
+        if (lane == 0) a.y[r * a.nout + o] = t + (a.b ? a.b[o] : 0.f);
+      }
+    }
+  }
+}
+
 // dx[r, :] = g[r] * w ; dw[c] += sum_r g[r] * x[r, c] ; db += sum_r g[r]   (column tiling as colsum)
 template <typename T>
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ g, const T* __restrict__ x,
@@ -821,6 +884,34 @@ extern "C" int case_rowdot_fwd(const void* x, const float* w, const float* b, fl
   else if (dtype == CASE_BF16) hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, b, y, rows, cols);
   else return case_set_error(CASE_E_UNSUPPORTED, "case_rowdot_fwd: dtype %d", dtype);
   return case_check_launch("case_rowdot_fwd");
+}
+
+extern "C" int case_linear_skinny(const void* const* xs, const int64_t* widths, int32_t nseg, const float* w, const float* b, float* y,
+                                  int64_t rows, int32_t nout, int32_t dtype, case_stream_t stream) {
+  CASE_REQUIRE(xs && widths && w && y && rows > 0 && nseg >= 1 && nseg <= 4 && nout >= 1 && nout <= 8, "case_linear_skinny: 1-4 inputs, 1-8 outputs");
+  SkinnyArgs a;
+  a.cols = 0;
+  for (int k = 0; k < 4; ++k) {
+    a.x[k] = k < nseg ? xs[k] : nullptr;
+    a.width[k] = k < nseg ? widths[k] : 0;
+    CASE_REQUIRE(k >= nseg || (xs[k] && widths[k] > 0), "case_linear_skinny: null or empty input %d", k);
+    a.cols += a.width[k];
+  }
+  a.w = w; a.b = b; a.y = y;
+  a.rows = rows; a.nseg = nseg; a.nout = nout;
+  const int grid = grid_for(rows, 4, 1, 256 * 8);
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = dtype == CASE_F32 ? 4 : 8;
+  bool vec = ((uintptr_t)w % 16) == 0 && a.cols % 4 == 0;
+  for (int k = 0; k < nseg; ++k) vec = vec && widths[k] % nv == 0 && ((uintptr_t)xs[k] % 16) == 0;
+  if (dtype == CASE_F32) {
+    if (vec) hipLaunchKernelGGL((linear_skinny_kernel<float, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((linear_skinny_kernel<float, false>), dim3(grid), dim3(256), 0, s, a);
+  } else if (dtype == CASE_BF16) {
+    if (vec) hipLaunchKernelGGL((linear_skinny_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((linear_skinny_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, s, a);
+  } else return case_set_error(CASE_E_UNSUPPORTED, "case_linear_skinny: dtype %d", dtype);
+  return case_check_launch("case_linear_skinny");
 }
 
 extern "C" int case_rowdot_bwd(const float* g, const void* x, const float* w, void* dx, float* dw, float* db, int64_t rows,

@@ -1898,18 +1898,23 @@ def additive_key_exp(uh):
     return eu
 
 
-def pointer_attend_decode(wq, eu, v, value, col_valid=None, row_valid=None, prior=None):
-    """wq f32 [B, H]; eu / value bf16 [B, S, H]; v f32 [H]; masks bool; prior f32 [B, S] -> (ctx bf16 [B, H], p f32 [B, S], copy f32 [B, S] | None)."""
+def pointer_attend_decode(wq, eu, v, value, col_valid=None, row_valid=None, prior=None, wq_add=None):
+    """wq f32 [B, H] (+ wq_add f32 [B, H]: a step-invariant part of the query projection, added in the kernel); eu / value bf16 [B, S, H]; v f32 [H];
+    masks bool; prior f32 [B, S] -> (ctx bf16 [B, H], p f32 [B, S], copy f32 [B, S] | None)."""
     B, S, H = value.shape
     wq = wq.reshape(B, H)
     wq = wq if wq.is_contiguous() else wq.contiguous()
+    if wq_add is not None:
+        wq_add = wq_add.reshape(B, H)
+        if wq_add.dtype != torch.float32 or not wq_add.is_contiguous():
+            raise TypeError("pointer_attend_decode: wq_add must be a contiguous f32 [B, H]")
     ctx = torch.empty(B, H, dtype=torch.bfloat16, device=value.device)
     p = torch.empty(B, S, dtype=torch.float32, device=value.device)
     copy = torch.empty_like(p) if prior is not None else None
     if prior is not None:
         prior = prior.reshape(B, S).float()
         prior = prior if prior.is_contiguous() else prior.contiguous()
-    A.call("case_pointer_attend_decode", _ptr(wq), _ptr(eu), _ptr(v), _ptr(value), _ptr(_u8(col_valid)), _ptr(_u8(row_valid)), _ptr(prior),
+    A.call("case_pointer_attend_decode", _ptr(wq), _ptr(wq_add), _ptr(eu), _ptr(v), _ptr(value), _ptr(_u8(col_valid)), _ptr(_u8(row_valid)), _ptr(prior),
            _ptr(ctx), _ptr(p), _ptr(copy), B, S, H, _stream())
     return ctx, p, copy
 
@@ -1923,6 +1928,32 @@ def pointer_head_supported(source_map, V, nmem):
     return (POINTER_HEAD != "off" and isinstance(source_map, SortedSource) and V <= 36000 and 1 <= nmem <= 4
             and not torch.is_grad_enabled()  # (no autograd Function behind K23)
             and bool(A.lib.case_abi_features() & A.FEAT_POINTER_HEAD))
+
+
+LINEAR_SKINNY = os.environ.get("CASE_LINEAR_SKINNY", "auto")  # "off": torch.cat + the GEMM path (A/B)
+
+
+def linear_skinny_supported(xs, w):
+    return (LINEAR_SKINNY != "off" and 1 <= len(xs) <= 4 and 1 <= w.shape[0] <= 8 and not torch.is_grad_enabled()
+            and all(x.is_cuda and x.dtype == xs[0].dtype and x.shape[:-1] == xs[0].shape[:-1] for x in xs)
+            and xs[0].dtype in (torch.float32, torch.bfloat16) and sum(x.shape[-1] for x in xs) == w.shape[1]
+            and bool(A.lib.case_abi_features() & A.FEAT_LINEAR_SKINNY))
+
+
+def linear_skinny(xs, w, b=None):
+    """Linear(sum widths, nout <= 8) on the column-wise concatenation of ``xs`` (1-4 tensors [..., width_k] of one dtype) WITHOUT forming it:
+    f32 [..., nout].  Weights and bias are used in f32 as they are (no bf16 copy).  No autograd (inference)."""
+    xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+    n = len(xs)
+    rows = xs[0].numel() // xs[0].shape[-1]
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    widths = (C.c_int64 * n)(*[x.shape[-1] for x in xs])
+    w32 = w.detach().float().contiguous()
+    b32 = None if b is None else b.detach().float().contiguous()
+    y = torch.empty(*xs[0].shape[:-1], w.shape[0], dtype=torch.float32, device=xs[0].device)
+    A.call("case_linear_skinny", C.cast(ptrs, C.c_void_p), C.cast(widths, C.c_void_p), n, _ptr(w32), _ptr(b32), _ptr(y), rows, w.shape[0], _code(xs[0]),
+           _stream())
+    return y
 
 
 def pointer_head_decode(logits, mix_logits, source_map, copies, want_gen=True, want_dist=True):

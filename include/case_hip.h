@@ -69,7 +69,8 @@ enum {
   CASE_FEAT_GEMM_LN = 1u << 13,         /* case_gemm_ln: LayerNorm prologue of the small-problem GEMM */
   CASE_FEAT_STEP_STATE = 1u << 14,      /* ABI 600: CaseStepState on the dropout sites and the optimizer, case_step_advance */
   CASE_FEAT_INTERACTION = 1u << 15,     /* K8 case_interaction_fwd: the dual co-attention as two kernels */
-  CASE_FEAT_ATTN_DECODE_APPEND = 1u << 16 /* case_attention_decode_append: the greedy step's cache append inside the attention launch */
+  CASE_FEAT_ATTN_DECODE_APPEND = 1u << 16, /* case_attention_decode_append: the greedy step's cache append inside the attention launch */
+  CASE_FEAT_LINEAR_SKINNY = 1u << 17      /* case_linear_skinny */
 };
 uint32_t case_abi_features(void);
 const char* case_last_error(void);
@@ -402,6 +403,13 @@ int case_rowdot_fwd(const void* x, const float* w, const float* b, float* y, int
                     case_stream_t stream);
 int case_rowdot_bwd(const float* g, const void* x, const float* w, void* dx, float* dw, float* db, int64_t rows,
                     int64_t cols, int32_t dtype, case_stream_t stream);
+/* few-output linear over a column-wise concatenation that is never formed (round 6): the greedy step's mixing logits, Linear(3H, 1 + nmem) on
+ * [dec_out | ctx_1 | .. ] (CaSE/Model.py:116, Masque/Model.py:42; common/TransformerSeqEncoderDecoder.py:141-142 of the reference's generic
+ * decoder): y[r, o] = sum_k xs[k][r, :] . w[o, off_k .. off_k + widths[k]) + b[o].  xs / widths: HOST arrays of nseg (1..4) device pointers
+ * ([rows, widths[k]] contiguous, `dtype`) and their widths; w f32 [nout, sum widths], b f32 [nout] (nullable), y f32 [rows, nout], nout 1..8.
+ * Inference only (no backward).  CASE_FEAT_LINEAR_SKINNY. */
+int case_linear_skinny(const void* const* xs, const int64_t* widths, int32_t nseg, const float* w, const float* b, float* y, int64_t rows,
+                       int32_t nout, int32_t dtype, case_stream_t stream);
 /* masked mean over the sequence: common/Utils.py:455-470.  x [n, L, H], valid u8 [n, L] -> out [n, H] */
 int case_masked_mean_fwd(const void* x, const uint8_t* valid, void* out, int64_t n, int64_t L, int64_t H,
                          int32_t dtype, case_stream_t stream);
@@ -467,7 +475,9 @@ int case_additive_scores_bwd(const float* ds, const float* wq, const void* uh, c
  * with tanh(a + b) = 1 - 2 / (e^{2a} e^{2b} + 1) and eu = e^{2 uh} CACHED across the steps (case_additive_key_exp: f32 uh -> bf16 eu, both
  * exponents clamped at +-43): one reciprocal per element instead of an exponential and a reciprocal.  wq [B, H] f32 (query projection incl.
  * bias), eu / value [B, S, H] bf16, v [H] f32, col_valid [B, S] / row_valid [B] bytes (nullable), prior [B, S] f32 (nullable, with copy);
- * outputs ctx [B, H] bf16, p [B, S] f32, copy [B, S] f32.  One workgroup per item; H = 512, S <= 28000; CASE_E_UNSUPPORTED otherwise. */
+ * outputs ctx [B, H] bf16, p [B, S] f32, copy [B, S] f32.  One workgroup per item; H = 512, S <= 28000; CASE_E_UNSUPPORTED otherwise.
+ * wq_add [B, H] f32 (nullable, round 6): added to wq -- the step-invariant part of the query projection when the query is [x_t | feature] with a
+ * feature that does not change over the steps (CaSE/Model.py:77-78: the answer representation), so that a step projects x_t alone. */
 int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_stream_t stream);
 /* K23 (round 5), the greedy step's pointer-generator head in one launch (CaSE/Model.py:34-48, :112-117; Masque/Model.py:29-44; argmax as
  * common/Utils.py:156-168, lowest index on ties):  gen = softmax(logits);  pm = softmax(mix_logits);
@@ -480,7 +490,7 @@ int case_additive_key_exp(const float* uh, void* eu, int64_t n, case_stream_t st
 int case_pointer_head_decode(const float* logits, const float* mix_logits, const uint32_t* keys, const float* const* copies,
                              const int64_t* lens, int32_t nmem, float* gen, float* dist, int64_t* ids, float* top, int64_t B, int64_t V,
                              int64_t S, case_stream_t stream);
-int case_pointer_attend_decode(const float* wq, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
+int case_pointer_attend_decode(const float* wq, const float* wq_add, const void* eu, const float* v, const void* value, const uint8_t* col_valid,
                                const uint8_t* row_valid, const float* prior, void* ctx, float* p, float* copy, int64_t B, int64_t S, int64_t H,
                                case_stream_t stream);
 /* ---------------------------------------------------------------------------------------------

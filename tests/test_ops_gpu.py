@@ -199,6 +199,26 @@ def test_attention_decode_append_equals_copy_then_attention(N, h, T, t):
             ops.attention_decode_append(qkv, a, T, h, d, key_valid=valid)  # position outside the cache
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,widths,nout", [(256, (512, 512, 512), 3), (33, (512,), 1), (7, (96, 40, 8, 24), 8), (300, (768, 768), 2)])
+def test_linear_skinny_equals_linear_on_the_concatenation(dt, rows, widths, nout):
+    """case_linear_skinny (the greedy step's mixing logits) against torch's Linear on the concatenated rows in f32: 1-4 inputs, 1-8 outputs,
+    widths that are not multiples of 64, more rows than waves in flight; and against the cat + GEMM path it replaces."""
+    ops = _ops()
+    xs = [_rand(rows, 1, w, dt=dt, seed=20 + i, scale=0.7) for i, w in enumerate(widths)]
+    W = _rand(nout, sum(widths), dt=torch.float32, seed=31, scale=0.1)
+    b = _rand(nout, dt=torch.float32, seed=32)
+    with torch.no_grad():
+        assert ops.linear_skinny_supported(xs, W)
+        y = ops.linear_skinny(xs, W, b)
+        old = ops.linear(torch.cat(xs, dim=-1), W, b, out_dtype=torch.float32)
+    ref = torch.cat([x.float() for x in xs], dim=-1) @ W.t() + b
+    assert y.shape == (rows, 1, nout) and y.dtype == torch.float32
+    _close(y, ref, 1e-4, "skinny linear vs f32 torch")  # (the inputs are exact in both: only the summation order differs)
+    _close(old, ref, 1e-4 if dt == torch.float32 else 2e-2, "cat + GEMM path vs f32 torch")
+    assert not ops.linear_skinny_supported(xs + xs + xs, W)  # > 4 inputs: the caller concatenates
+
+
 def test_softmax_masks_and_empty_rows():
     ops = _ops()
     x = _rand(2, 6, 9, seed=1).requires_grad_()

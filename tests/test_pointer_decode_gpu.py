@@ -53,6 +53,39 @@ def test_pointer_attend_decode_matches_f32_restatement(B, S, with_prior):
     # fixed-order sums: bit-identical from launch to launch
     ctx2, p2, _ = ops.pointer_attend_decode(wq, eu, v, mem, cv, rv, prior)
     assert torch.equal(ctx, ctx2) and torch.equal(p, p2)
+    # wq_add: the step-invariant part of the query projection is added inside the kernel, in f32 -- the same bits as the sum handed over whole
+    part = _rand(B, H, seed=6, scale=0.8)
+    ctx3, p3, copy3 = ops.pointer_attend_decode(wq - part, eu, v, mem, cv, rv, prior, wq_add=part)
+    ctx4, p4, copy4 = ops.pointer_attend_decode((wq - part) + part, eu, v, mem, cv, rv, prior)
+    assert torch.equal(ctx3, ctx4) and torch.equal(p3, p4) and (copy3 is None or torch.equal(copy3, copy4))
+
+
+def test_split_query_equals_the_concatenated_query():
+    """BilinearAttention.split_query + attend_decode(split=) (a step projects x_t alone, the feature half of the query projection is added in K22)
+    against attend_decode on the concatenated [x_t | feature] query: same module, same bf16 inputs; the two differ in f32 summation order only."""
+    from case_rg_amd import ops
+    from case_rg_amd.common.BilinearAttention import BilinearAttention
+    B, S, H = 64, 640, 512
+    m = BilinearAttention(2 * H, H, H).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_((torch.randn(prm.shape, generator=g) * 0.05).to(DEV))
+    x = _rand(B, 1, H, seed=12, dt=torch.bfloat16)
+    feat = _rand(B, 1, H, seed=13, dt=torch.bfloat16)
+    mem = _rand(B, S, H, seed=14, dt=torch.bfloat16)
+    cv = (torch.rand(B, S, generator=g) < 0.9).to(DEV)
+    cv[:, 0] = True
+    rv = torch.ones(B, 1, dtype=torch.bool, device=DEV)
+    prior = torch.rand(B, S, generator=g).to(DEV)
+    with torch.no_grad():
+        eu = m.project_keys_exp(mem)
+        c1, p1 = m.attend_decode(torch.cat([x, feat], dim=-1), mem, rv, cv, eu, prior)
+        split = m.split_query(feat, H)
+        c2, p2 = m.attend_decode(x, mem, rv, cv, eu, prior, split=split)
+    assert split[0].shape == (H, H) and split[1].shape == (B, H) and split[1].dtype == torch.float32
+    assert (p1 - p2).abs().max().item() <= 1e-4 * p1.abs().max().item() + 1e-7
+    assert (c1.float() - c2.float()).abs().max().item() <= 1e-2 * c1.float().abs().max().item()
 
 
 def test_attend_decode_agrees_with_the_four_launch_form():
