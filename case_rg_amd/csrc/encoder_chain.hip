@@ -98,10 +98,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t as_rsrc(const void* p, uint32_
   const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(size_t)p), hi = __builtin_amdgcn_readfirstlane((int)(((size_t)p) >> 32));
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
+// The token tile is read once, by one workgroup: requested non-temporal (north-star point 7.16 -> 7.12 ms, three alternating pairs on one box;
+// -DCASE_STREAM_DEFAULT_POLICY: the default cache policy, for A/B builds).
+#ifndef CASE_STREAM_DEFAULT_POLICY
+#define CHAIN_NT " nt"
+#else
+#define CHAIN_NT ""
+#endif
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" CHAIN_NT " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
