@@ -66,7 +66,15 @@ template <> struct Vec16<bf16_t> {
       v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
   }
+#ifdef CASE_VEC16_NT
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+    const u32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    unpack(make_uint4(t[0], t[1], t[2], t[3]), v);
+  }
+#else
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
+#endif
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll

@@ -3,6 +3,12 @@
 // wavefront shuffles for the reductions, f32 statistics regardless of the storage dtype.
 #include <stdlib.h>
 
+// The row kernels of this file read every tensor once (the LayerNorm input and its incoming gradient are not touched again before the backward pass
+// / at all), so their 16-byte loads are non-temporal: the rows they WRITE -- the next GEMM's operand -- keep the Infinity Cache.  Training step
+// 95.14 / 94.95 -> 94.89 / 94.68 ms (alternating pairs, one box).  -DCASE_STREAM_DEFAULT_POLICY: the default policy (A/B builds).
+#ifndef CASE_STREAM_DEFAULT_POLICY
+#define CASE_VEC16_NT
+#endif
 #include "common.h"
 
 namespace {
