@@ -95,7 +95,43 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_adam_ema_kernel(const CaseO
     step_size = a.state->step_size;
     bc2_sqrt = a.state->bc2_sqrt;
   }
-  for (int64_t i = begin + threadIdx.x; i < end; i += OPT_THREADS) {
+  // Round 6: 16-byte non-temporal accesses where every stream of the entry is 16-byte aligned (a chunk starts at a multiple of 16 384 elements):
+  // parameter, gradient, both moments and the shadow are read and written ONCE per step and next touched a step later -- they need not displace
+  // the bf16 operand copies (the one output the next forward pass reads) from the Infinity Cache.  The arithmetic per element is adam_one's, in the
+  // same order: results are bit-identical to the scalar loop below, which stays for unaligned views (gradients inside a flat bucket).
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  const uintptr_t align = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                          reinterpret_cast<uintptr_t>(sh) | (reinterpret_cast<uintptr_t>(lp) << 1);
+  const bool ema = sh && a.ema_w > 0.f;
+  int64_t done = begin;
+#ifndef CASE_STREAM_DEFAULT_POLICY
+  if ((align & 15) == 0) {
+    const int64_t nv = (end - begin) / 4;
+    for (int64_t q = threadIdx.x; q < nv; q += OPT_THREADS) {
+      const int64_t i = begin + 4 * q;
+      f32x4_nt pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p + i));
+      const f32x4_nt gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(g + i));
+      f32x4_nt mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(m + i));
+      f32x4_nt vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(v + i));
+      f32x4_nt sv = {0.f, 0.f, 0.f, 0.f};
+      if (ema) sv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(sh + i));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pe = pv[e], me = mv[e], ve = vv[e];
+        adam_one(pe, gv[e], me, ve, a, clip, step_size, bc2_sqrt);
+        pv[e] = pe; mv[e] = me; vv[e] = ve;
+        if (ema) sv[e] = sv[e] + a.ema_w * (pe - sv[e]);
+      }
+      __builtin_nontemporal_store(pv, reinterpret_cast<f32x4_nt*>(p + i));
+      __builtin_nontemporal_store(mv, reinterpret_cast<f32x4_nt*>(m + i));
+      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_nt*>(v + i));
+      if (ema) __builtin_nontemporal_store(sv, reinterpret_cast<f32x4_nt*>(sh + i));
+      if (lp) *reinterpret_cast<uint2*>(lp + i) = make_uint2(f32x2_to_bf16x2(pv[0], pv[1]), f32x2_to_bf16x2(pv[2], pv[3]));
+    }
+    done = begin + 4 * nv;
+  }
+#endif
+  for (int64_t i = done + threadIdx.x; i < end; i += OPT_THREADS) {
     float pi = p[i], mi = m[i], vi = v[i];
     adam_one(pi, g[i], mi, vi, a, clip, step_size, bc2_sqrt);
     p[i] = pi;
