@@ -13,7 +13,7 @@ from ..common.Constants import BOS_WORD, EOS_WORD, UNK_WORD
 from ..common.Interaction import Interaction
 from ..common.TransformerSeqEncoderDecoder import PointerDecoderCore, TransformerSeqEncoder
 from ..common.Utils import to_sentence
-from ..common.heads import block_stack, generation_nll, passage_bce, run_blocks
+from ..common.heads import block_stack, generation_nll, passage_bce, run_block_pair, run_blocks
 
 
 class CaSETransformerSeqDecoder(PointerDecoderCore):
@@ -92,8 +92,7 @@ class RelevantPassageSelection(nn.Module):
         eq, ep = encode_query[0][:, :, -1], encode_passage[0][:, :, -1]
         passage_mask, query_mask = passage.ne(0), query.ne(0)
         g_pq, g_qp = self.interaction(eq, ep, query_mask, passage_mask)
-        query_reps = run_blocks(self.query_blocks, g_pq, query_mask)
-        passage_reps = run_blocks(self.passage_blocks, g_qp, passage_mask)
+        query_reps, passage_reps = run_block_pair(self.query_blocks, g_pq, query_mask, self.passage_blocks, g_qp, passage_mask)
         cls = passage_reps[:, :, 0].contiguous()
         score = ops.linear(cls, self.scorer.weight, self.scorer.bias, out_dtype=torch.float32).squeeze(-1)
         return score, (query_reps, query_reps[:, :, 0]), (passage_reps, passage_reps[:, :, 0])
@@ -122,8 +121,7 @@ class SupportingTokenIdentification(nn.Module):
         passage_mask, query_mask = passage.ne(0), query.ne(0)
         _, query_rep, passage_rep = passage_selection_result
         g_pq, g_qp = self.interaction(query_rep[0], passage_rep[0], query_mask, passage_mask)
-        query_reps = run_blocks(self.query_blocks, g_pq, query_mask)
-        passage_reps = run_blocks(self.passage_blocks, g_qp, passage_mask)
+        query_reps, passage_reps = run_block_pair(self.query_blocks, g_pq, query_mask, self.passage_blocks, g_qp, passage_mask)
         token_score = ops.linear(passage_reps, self.scorer.weight, self.scorer.bias, out_dtype=torch.float32).squeeze(-1)
         token_score = token_score.masked_fill(~passage_mask, -1e6).clamp(min=-1e6, max=1e6)
         query_reps = ops.layer_norm(query_rep[0], self.norm1.weight, self.norm1.bias, self.norm1.eps, add=query_reps)

@@ -8,7 +8,7 @@ from ..common.Constants import BOS_WORD, EOS_WORD, UNK_WORD
 from ..common.Interaction import Interaction
 from ..common.TransformerSeqEncoderDecoder import PointerDecoderCore, TransformerSeqEncoder
 from ..common.Utils import to_sentence
-from ..common.heads import block_stack, generation_nll, passage_bce, run_blocks
+from ..common.heads import block_stack, generation_nll, passage_bce, run_block_pair
 
 
 class MasqueTransformerSeqDecoder(PointerDecoderCore):
@@ -81,8 +81,7 @@ class PassageSelection(nn.Module):
             encode_passage = self.passage_encoder(passage)[0][:, :, -1]
         passage_mask, query_mask = passage.ne(0), query.ne(0)
         g_pq, g_qp = self.interaction(encode_query, encode_passage, query_mask, passage_mask)
-        query_reps = run_blocks(self.query_blocks, g_pq, query_mask)
-        passage_reps = run_blocks(self.passage_blocks, g_qp, passage_mask)
+        query_reps, passage_reps = run_block_pair(self.query_blocks, g_pq, query_mask, self.passage_blocks, g_qp, passage_mask)
         cls = passage_reps[:, :, 0].contiguous()
         score = ops.linear(cls, self.scorer.weight, self.scorer.bias, out_dtype=torch.float32).squeeze(-1)
         return score, query_reps, passage_reps

@@ -185,3 +185,49 @@ def test_backward_with_slabs_is_bit_reproducible_over_twenty_launches(settings):
         err = (runs[0][n] - runs[1][n]).abs().max().item() / (runs[0][n].abs().max().item() + 1e-30)
         assert err <= 2e-3, (n, err)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_query_side_stack_on_a_second_stream_changes_nothing(settings, dt):
+    """Round 6: in training the query-side block stacks run on a second stream beside the passage-side stacks (common/heads.run_block_pair).
+    Same model, same ragged batch, dropout ON (the masks are numbered by the host in creation order, which the two modes share): the three
+    losses and EVERY parameter gradient of the two-stream step against the one-stream step -- the differences are those of two executions of
+    one mode (f32 atomics), and the second stream must actually have been used."""
+    from case_rg_amd.common import heads
+    from case_rg_amd.utils import synth_batch
+    settings.set_compute_dtype(dt)
+    settings.set_dropout(True)
+    model = _model()
+    batch = {k: v.to(DEV) for k, v in synth_batch(4, P, LP, LQ, T, V, seed=7, ragged=True, model="case").items()}
+    from case_rg_amd import config
+
+    def run(side):
+        keep, heads.SIDE_STREAM = heads.SIDE_STREAM, side
+        try:
+            config.set_rng_state((1234, 0))
+            model.train()
+            model.zero_grad(set_to_none=True)
+            losses = model(dict(batch), method="train")
+            torch.cat([l.mean().reshape(1) for l in losses]).sum().backward()
+            torch.cuda.synchronize()
+            return [float(l.mean()) for l in losses], {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            heads.SIDE_STREAM = keep
+
+    heads._side.clear()
+    l1, g1 = run(False)
+    assert not heads._side, "the one-stream step created a side stream"
+    l1b, g1b = run(False)
+    l2, g2 = run(True)
+    assert heads._side, "the two-stream step never left the calling stream"
+    tol = 1e-5 if dt == torch.float32 else 2e-3
+    for a, b in zip(l1, l2):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), "losses differ: %s vs %s" % (l1, l2)
+    assert g1.keys() == g2.keys()
+    worst_noise = worst = 0.0
+    for n in g1:
+        scale = g1[n].abs().max().item() + 1e-12
+        worst_noise = max(worst_noise, (g1[n] - g1b[n]).abs().max().item() / scale)
+        worst = max(worst, (g1[n] - g2[n]).abs().max().item() / scale)
+    print("second stream: worst gradient difference %.2e of the tensor's scale (two one-stream executions: %.2e)" % (worst, worst_noise))
+    assert worst <= max(4.0 * worst_noise, 1e-5 if dt == torch.float32 else 2e-3), "gradients differ by %.3e (run-to-run noise %.3e)" % (worst, worst_noise)
