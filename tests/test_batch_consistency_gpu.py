@@ -203,6 +203,7 @@ def test_query_side_stack_on_a_second_stream_changes_nothing(settings, dt):
 
     def run(side):
         keep, heads.SIDE_STREAM = heads.SIDE_STREAM, side
+        keep_min, heads.SIDE_STREAM_MIN_ELEMS = heads.SIDE_STREAM_MIN_ELEMS, 0  # (the policy reserves the second stream for GPU-bound geometries)
         try:
             config.set_rng_state((1234, 0))
             model.train()
@@ -212,7 +213,7 @@ def test_query_side_stack_on_a_second_stream_changes_nothing(settings, dt):
             torch.cuda.synchronize()
             return [float(l.mean()) for l in losses], {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
         finally:
-            heads.SIDE_STREAM = keep
+            heads.SIDE_STREAM, heads.SIDE_STREAM_MIN_ELEMS = keep, keep_min
 
     heads._side.clear()
     l1, g1 = run(False)
