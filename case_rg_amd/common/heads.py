@@ -42,6 +42,8 @@ def run_block_pair(query_blocks, g_pq, query_mask, passage_blocks, g_qp, passage
     side = _side.get(g_pq.device)
     if side is None:
         side = _side[g_pq.device] = torch.cuda.Stream(device=g_pq.device)
+    ops.AUX_STREAMS[side.cuda_stream] = side  # (whoever gathers gradients across nodes -- parallel.GradSync -- joins these first)
+    ops.AUX_STREAMS[cur.cuda_stream] = cur
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         # tensors of the calling stream's pool that side-stream kernels read, in this pass and (saved) in the backward pass: the allocator must not

@@ -196,6 +196,22 @@ def encoder_chain(variant, x_in, resid, layer, next_layer):
 # Tiling of the GEMM calls issued from here: 0 = case_gemm's cost model, 128 / 256 = CaseGemmDesc.tile (tests and A/B
 # measurements run the same model under both tilings).  Host-side configuration: the library itself holds no state.
 GEMM_TILE = 0
+# Streams the package itself has put work on beside the caller's (common/heads.run_block_pair), by handle.  A backward pass then runs nodes -- and
+# their post-accumulate hooks -- on more than one stream: code that reads SEVERAL parameters' gradients from inside such a hook (parallel.GradSync)
+# calls join_aux_streams() first.
+AUX_STREAMS = {}
+
+
+def join_aux_streams():
+    """The current stream waits for everything queued so far on the other streams this package uses."""
+    if not AUX_STREAMS:
+        return
+    cur = torch.cuda.current_stream()
+    for handle, s in AUX_STREAMS.items():
+        if handle != cur.cuda_stream:
+            cur.wait_stream(s)
+
+
 # Measurement aid (bench.py): when a list, every launch appends the tile edge case_gemm_tile_for() reports for it.
 TILE_TRACE = None
 # Fewest (sequence, head) pairs for which the one-workgroup-per-pair decode attention kernel is used (below: split-KV forward)
@@ -282,13 +298,19 @@ def _split_for(out_rows, out_cols, k_len, elem_bytes):
     if (elem_bytes == 2 and out_rows % 256 == 0 and out_cols % 256 == 0 and k_len % 64 == 0 and k_tiles >= 64
             and tiles256 * min(64, k_tiles // 8) >= 230):
         tiles = tiles256
+        # rounds of the PERSISTENT grid as it is right now: under data parallelism GradSync keeps 8 CUs for RCCL during the backward pass
+        # (case_set_reserved_cus), and splits chosen for 256 workgroups then land just past a round of 248 -- 300 x 5 work items = 6.05
+        # rounds, 100 x 5 = 2.02: the forced one-rank group paid 3 ms per step for that alone
+        cus = max(8, (256 - int(A.lib.case_get_reserved_cus())) // 8 * 8)
         best, best_score = 1, -1.0
         for split in range(1, 65):
             if split > 1 and k_tiles // split < 8:
                 break
             wgs = tiles * split
-            eff = wgs / (((wgs + 255) // 256) * 256.0)
-            score = eff - 0.004 * split - (0.5 if wgs < 230 else 0.0)  # every extra split is another pass of f32 atomics over C
+            eff = wgs / float(((wgs + cus - 1) // cus) * cus)
+            # every extra split is another pass over C: slab stores + an ordered reduce at the HBM rate for the small outputs (0.4 % of the launch
+            # each), f32 atomics at ~1.3 TB/s for the large ones (1.2 %)
+            score = eff - (0.012 if tiles >= 64 else 0.004) * split - (0.5 if wgs < 0.9 * cus else 0.0)
             if score > best_score:
                 best, best_score = split, score
         return best

@@ -131,6 +131,9 @@ class GradSync:
         """Gather the bucket's gradients into its flat buffer (one multi-tensor copy; gradients that already ARE the bucket
         views, e.g. after an accumulation micro-step, need none) and start the asynchronous all-reduce."""
         self._reserve(True)
+        if b["flat"].is_cuda:
+            from . import ops
+            ops.join_aux_streams()  # the bucket's gradients may have been produced on another stream than the one this hook runs on
         src, dst = [], []
         for (p, off, n), view in zip(b["items"], b["views"]):
             if p.grad is None:

@@ -187,10 +187,17 @@ def test_full_size_properties_cfg2_shapes(ns):
         case_rg_amd.set_compute_dtype(torch.float32)
 
 
-def test_gradsync_over_rccl_on_one_rank(ns):
+@pytest.mark.parametrize("second_stream", [False, True])
+def test_gradsync_over_rccl_on_one_rank(ns, second_stream):
     """Drives the data-parallel machinery (post-accumulate hooks -> flat buckets -> asynchronous RCCL all-reduce ->
-    scatter back) on a one-rank "nccl" group on the GPU: the synchronised gradients must equal the plain ones."""
+    scatter back) on a one-rank "nccl" group on the GPU: the synchronised gradients must equal the plain ones.
+    ``second_stream``: with the query-side block stacks on their own stream (common/heads.run_block_pair; forced here, the policy reserves it for
+    GPU-bound geometries) the hooks fire on two streams -- GradSync joins them before it gathers a bucket (ops.join_aux_streams)."""
     import socket
+    from case_rg_amd.common import heads
+    keep_min = heads.SIDE_STREAM_MIN_ELEMS
+    if second_stream:
+        heads.SIDE_STREAM_MIN_ELEMS = 0
     import torch.distributed as dist
     from case_rg_amd.parallel import GradSync
     from case_rg_amd.utils import fill_params, make_vocab, synth_batch
@@ -217,7 +224,9 @@ def test_gradsync_over_rccl_on_one_rank(ns):
             scale = plain[n].abs().max().item() + 1e-12
             err = (p.grad - plain[n]).abs().max().item()
             assert err <= 1e-4 * scale, "%s: %.3e vs scale %.3e" % (n, err, scale)
+        assert bool(heads._side) or not (second_stream and heads.SIDE_STREAM), "the second stream was never used"
     finally:
+        heads.SIDE_STREAM_MIN_ELEMS = keep_min
         dist.destroy_process_group()
 
 
