@@ -51,7 +51,7 @@ class GradSync:
                 self._close_bucket(cur, cur_n)
                 cur, cur_n = [], 0
             cur.append((p, cur_n, p.numel()))
-            cur_n += p.numel()
+            cur_n += (p.numel() + 3) // 4 * 4  # every view starts on a 16-byte boundary (the optimizer kernel's vector path; the padding stays zero)
         if cur:
             self._close_bucket(cur, cur_n)
         self.broadcast_parameters(model)
