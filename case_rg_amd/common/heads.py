@@ -2,6 +2,7 @@
 import os
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -30,6 +31,7 @@ SIDE_STREAM = os.environ.get("CASE_SIDE_STREAM", "1") != "0"
 # (inference: measured on the greedy pass at B = 256 -- the encode phase gains 0.4 ms of 183, the 63 cached steps behind it LOSE 0.04 ms each
 #  (2.5 ms): off unless asked for)
 SIDE_STREAM_INFERENCE = os.environ.get("CASE_SIDE_STREAM_INFERENCE", "0") == "1"
+SIDE_STREAM_NOT_UNDER_DP = os.environ.get("CASE_SIDE_STREAM_UNDER_DP", "0") != "1"
 SIDE_STREAM_MIN_ELEMS = 100_000_000  # elements of the passage-side input [B, P, Lp, 5H]
 _side = {}
 
@@ -38,8 +40,10 @@ def run_block_pair(query_blocks, g_pq, query_mask, passage_blocks, g_qp, passage
     """(query_reps, passage_reps) of two independent block stacks."""
     # (only where the passage side is GPU-bound: at the reference's default geometry -- 16 000 passage rows, a host-bound step -- the second
     #  stream's bookkeeping COSTS 2.3 ms of 19.4; cfg 2 / cfg 5 / Masque B 32 hand over 3.1e8 elements, Masque B 8 7.9e7 (neutral))
+    # (not under data parallelism: GradSync keeps 8 CUs free for RCCL during the backward pass, the side stream's launches then start at once
+    #  ON THOSE 8 CUs and crawl -- forced one-rank group: 96.8 ms with one stream, 99.3 with two)
     if not (SIDE_STREAM and g_pq.is_cuda and g_qp.numel() >= SIDE_STREAM_MIN_ELEMS and (torch.is_grad_enabled() or SIDE_STREAM_INFERENCE)
-            and not torch.cuda.is_current_stream_capturing()):
+            and not torch.cuda.is_current_stream_capturing() and not (SIDE_STREAM_NOT_UNDER_DP and dist.is_available() and dist.is_initialized())):
         return run_blocks(query_blocks, g_pq, query_mask), run_blocks(passage_blocks, g_qp, passage_mask)
     cur = torch.cuda.current_stream()
     side = _side.get(g_pq.device)

@@ -98,6 +98,7 @@ class GradSync:
         finally:
             for b in self.buckets:
                 b["work"], b["pending"] = None, len(b["items"])
+                b.pop("events", None)
             self._next = 0
             self._reserve(False)
 
@@ -106,6 +107,15 @@ class GradSync:
             return
         b = self.buckets[self._slot[id(p)]]
         b["pending"] -= 1
+        if p.is_cuda:
+            # the hook runs on the stream that produced this gradient (the package puts the query-side block stacks on a second stream:
+            # common/heads.run_block_pair); whoever gathers the bucket -- maybe a hook on the OTHER stream -- waits for exactly this point,
+            # not for everything queued on that stream
+            from . import ops
+            if ops.AUX_STREAMS:
+                ev = torch.cuda.Event()
+                ev.record()
+                b.setdefault("events", []).append(ev)
         self._launch_ready()
 
     def _launch_ready(self, flush=False):
@@ -131,9 +141,10 @@ class GradSync:
         """Gather the bucket's gradients into its flat buffer (one multi-tensor copy; gradients that already ARE the bucket
         views, e.g. after an accumulation micro-step, need none) and start the asynchronous all-reduce."""
         self._reserve(True)
-        if b["flat"].is_cuda:
-            from . import ops
-            ops.join_aux_streams()  # the bucket's gradients may have been produced on another stream than the one this hook runs on
+        if b["flat"].is_cuda:  # the bucket's gradients may have been produced on another stream than the one this launch runs on
+            cur = torch.cuda.current_stream()
+            for ev in b.pop("events", ()):
+                cur.wait_event(ev)
         src, dst = [], []
         for (p, off, n), view in zip(b["items"], b["views"]):
             if p.grad is None:

@@ -196,8 +196,10 @@ def test_gradsync_over_rccl_on_one_rank(ns, second_stream):
     import socket
     from case_rg_amd.common import heads
     keep_min = heads.SIDE_STREAM_MIN_ELEMS
+    keep_dp = heads.SIDE_STREAM_NOT_UNDER_DP
     if second_stream:
         heads.SIDE_STREAM_MIN_ELEMS = 0
+        heads.SIDE_STREAM_NOT_UNDER_DP = False  # (the policy keeps the second stream out of data-parallel runs: the reserved CUs; forced here)
     import torch.distributed as dist
     from case_rg_amd.parallel import GradSync
     from case_rg_amd.utils import fill_params, make_vocab, synth_batch
@@ -226,7 +228,7 @@ def test_gradsync_over_rccl_on_one_rank(ns, second_stream):
             assert err <= 1e-4 * scale, "%s: %.3e vs scale %.3e" % (n, err, scale)
         assert bool(heads._side) or not (second_stream and heads.SIDE_STREAM), "the second stream was never used"
     finally:
-        heads.SIDE_STREAM_MIN_ELEMS = keep_min
+        heads.SIDE_STREAM_MIN_ELEMS, heads.SIDE_STREAM_NOT_UNDER_DP = keep_min, keep_dp
         dist.destroy_process_group()
 
 
